@@ -1,0 +1,61 @@
+# Build recipe for the MI355X-native detect engine (gfx950 only) and its test infrastructure.
+#   make            -> libzly.so (HIP engine + C ABI), libzly_plugin.so (IInferenceEngine host side),
+#                      host test binary, CPU oracle, synthetic weight files
+#   make oracle     -> oracle/_build/libzly_oracle.so only (gcc, no GPU toolchain needed)
+PKG      := zero-latency-yolo_amd
+CSRC     := $(PKG)/csrc
+HOST     := $(PKG)/host
+OUT      := $(PKG)/_build
+HIPCC    ?= hipcc
+ARCH     ?= gfx950
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -I$(CSRC) -Wall -Wno-unused-function -Wno-unused-result -Wno-unused-value
+CXX      ?= g++
+PY       ?= python3
+
+KERNELS  := $(CSRC)/kernels_conv.hip $(CSRC)/kernels_misc.hip $(CSRC)/kernels_post.hip
+ENGINE   := $(CSRC)/engine.cpp $(CSRC)/weights.cpp
+OBJS     := $(OUT)/kernels_conv.o $(OUT)/kernels_misc.o $(OUT)/kernels_post.o $(OUT)/engine.o $(OUT)/weights.o
+
+all: $(OUT)/libzly.so oracle weights host
+
+$(OUT):
+	mkdir -p $(OUT)
+
+$(OUT)/%.o: $(CSRC)/%.hip $(CSRC)/zly_internal.h include/zly.h | $(OUT)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(OUT)/engine.o: $(CSRC)/engine.cpp $(CSRC)/zly_internal.h $(CSRC)/weights.h include/zly.h | $(OUT)
+	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
+
+$(OUT)/weights.o: $(CSRC)/weights.cpp $(CSRC)/weights.h include/zly.h | $(OUT)
+	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
+
+$(OUT)/libzly.so: $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+
+# ---- host side: the reference's IInferenceEngine plugin interface over the C ABI -----------------
+host: $(OUT)/libzly_plugin.so $(OUT)/test_hip_engine
+
+$(OUT)/libzly_plugin.so: $(HOST)/hip_inference_engine.cpp $(HOST)/hip_inference_engine.h $(HOST)/zly_compat.hpp include/zly.h $(OUT)/libzly.so
+	$(CXX) -O2 -std=c++17 -fPIC -shared -Iinclude -I$(HOST) -o $@ $(HOST)/hip_inference_engine.cpp -L$(OUT) -lzly -pthread -Wl,-rpath,'$$ORIGIN'
+
+$(OUT)/test_hip_engine: tests/cpp/test_hip_engine.cpp $(OUT)/libzly_plugin.so
+	$(CXX) -O2 -std=c++17 -Iinclude -I$(HOST) -o $@ tests/cpp/test_hip_engine.cpp -L$(OUT) -lzly_plugin -lzly -pthread -Wl,-rpath,'$$ORIGIN'
+
+# ---- CPU oracle (test infrastructure only) --------------------------------------------------------
+oracle: oracle/_build/libzly_oracle.so
+
+oracle/_build/libzly_oracle.so: oracle/zly_oracle.c
+	mkdir -p oracle/_build
+	gcc -O2 -ffp-contract=off -fno-fast-math -shared -fPIC -o $@ $<
+
+# ---- seeded synthetic weights (no real weights exist offline) --------------------------------------
+weights: $(OUT)/yolov8n_synth.zlyw
+
+$(OUT)/yolov8n_synth.zlyw: $(PKG)/tools/zly_model.py | $(OUT)
+	$(PY) $(PKG)/tools/zly_model.py --scale n -o $@
+
+clean:
+	rm -rf $(OUT) oracle/_build
+
+.PHONY: all host oracle weights clean

@@ -1,0 +1,314 @@
+"""GPU parity tests (run on the MI355X box: pytest -m gpu).  Every call goes through the C ABI of
+libzly.so; the CPU oracle (oracle/) is only the checker.
+
+Tolerances (stated here, used below):
+  * preprocess, decode, NMS: BIT-EXACT against oracle/zly_oracle.c (integer / single-rounded fp32 work).
+  * fp32 engine head tensor vs fp32 oracle: box rows <= FP32_BOX_TOL px, score rows <= FP32_SCORE_TOL
+    (summation-order differences of an exact-fp32 MFMA chain vs MLAS/oneDNN only).
+  * bf16 engine vs the bf16-rounding-emulating oracle: BF16E_* ; vs the plain fp32 oracle: BF16_* .
+"""
+import numpy as np
+import pytest
+import torch
+
+import zly
+import zly_model as zm
+from oracle_lib import det_fields_equal
+
+pytestmark = pytest.mark.gpu
+
+FP32_BOX_TOL = 5e-3      # px (values reach ~800 px: 6e-6 relative)
+FP32_SCORE_TOL = 1e-4
+BF16E_BOX_TOL = 1.0      # px, bf16 engine vs bf16-emulating oracle
+BF16E_SCORE_TOL = 1.5e-2
+BF16_BOX_TOL = 4.0       # px, bf16 engine vs fp32 oracle (boxes up to ~800 px: 0.5 %)
+BF16_SCORE_TOL = 4e-2
+F6 = ["x", "y", "w", "h", "confidence", "class_id"]
+
+
+@pytest.fixture(scope="module")
+def eng32(weights_path):
+    e = zly.Engine(weights_path, dtype=zly.DTYPE_FP32, max_batch=4, max_dets=512, warmup_runs=1)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def eng16(weights_path):
+    e = zly.Engine(weights_path, dtype=zly.DTYPE_BF16, max_batch=8, max_dets=512, warmup_runs=1)
+    yield e
+    e.close()
+
+
+def _pre(oracle, frames, tw=416, th=416):
+    return np.stack([oracle.preprocess(f, tw, th)[1] for f in frames])
+
+
+# ---------------------------------------------------------------------------------------------------
+# preprocess: bit-exact
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("w,h", [(416, 416), (800, 600), (64, 48), (1920, 1080), (417, 415), (1, 1)])
+def test_preprocess_bit_exact(eng16, oracle, w, h):
+    rng = np.random.default_rng(w * 10007 + h)
+    img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    rc, want = oracle.preprocess(img, 416, 416)
+    assert rc == 0
+    got = eng16.preprocess(img)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_preprocess_constant_128(eng32):
+    got = eng32.preprocess(np.full((416, 416, 3), 128, dtype=np.uint8))
+    assert np.all(got == np.float32(128) / np.float32(255.0))
+
+
+def test_preprocess_wrong_byte_count_is_error_203(eng16):
+    img = np.zeros((10, 10, 3), dtype=np.uint8)
+    with pytest.raises(zly.ZlyError) as ei:
+        eng16.preprocess(img, nbytes=299)
+    assert ei.value.code == zly.ERR_INVALID_INPUT and "expected 300" in ei.value.message
+    with pytest.raises(zly.ZlyError) as ei:
+        eng16.detect(img, nbytes=301)
+    assert ei.value.code == zly.ERR_INVALID_INPUT
+
+
+# ---------------------------------------------------------------------------------------------------
+# decode + NMS: bit-exact on caller-supplied head tensors
+# ---------------------------------------------------------------------------------------------------
+def _rand_head(rng, nc, n, hot=0.02, size=416):
+    head = np.zeros((4 + nc, n), dtype=np.float32)
+    head[0] = rng.uniform(0, size, n); head[1] = rng.uniform(0, size, n)
+    head[2] = rng.uniform(8, size / 2, n); head[3] = rng.uniform(8, size / 2, n)
+    head[4:] = rng.uniform(0, 0.45, (nc, n))
+    idx = rng.choice(n, max(1, int(hot * n)), replace=False)
+    head[4 + rng.integers(0, nc, len(idx)), idx] = rng.uniform(0.5, 1.0, len(idx))
+    return head
+
+
+@pytest.mark.parametrize("nc,n,hot,seed", [(80, 3549, 0.02, 0), (80, 3549, 0.2, 1), (4, 8400, 0.05, 2), (1, 1000, 0.3, 3),
+                                           (80, 3549, 0.6, 4), (3, 777, 0.1, 5), (80, 64, 0.5, 6)])
+def test_postprocess_bit_exact(eng16, oracle, nc, n, hot, seed):
+    head = _rand_head(np.random.default_rng(seed), nc, n, hot)
+    want = oracle.postprocess(head, 800, 600)
+    got, n_kept, n_cand = eng16.postprocess(head, 800, 600)
+    assert n_cand == len(oracle.decode(head, 800, 600))
+    assert n_kept == len(want)
+    assert det_fields_equal(got, want)
+
+
+def test_postprocess_many_candidates_in_one_class(eng16, oracle):
+    """> 1024 candidates of ONE class: exercises the global-memory NMS path and long greedy chains."""
+    rng = np.random.default_rng(9)
+    head = _rand_head(rng, 2, 3000, 0.0)
+    head[4] = rng.uniform(0.5, 1.0, 3000)
+    head[5] = 0
+    want = oracle.postprocess(head, 416, 416)
+    got, n_kept, n_cand = eng16.postprocess(head, 416, 416)
+    assert n_cand == 3000 and n_kept == len(want) and det_fields_equal(got, want)
+
+
+def test_postprocess_ties_threshold_and_empty(eng16, oracle):
+    head = np.zeros((4 + 4, 8), dtype=np.float32)
+    head[0] = [50, 60, 300, 300, 300, 100, 100, 100]; head[1] = 100
+    head[2] = 80; head[3] = 80
+    half_minus = np.nextafter(np.float32(0.5), np.float32(0))
+    head[4] = [0.5, half_minus, 0.8, 0.8, 0.8, 0, 0, 0]      # inclusive threshold; exact ties
+    head[5] = [0.0, 0.0, 0.8, 0.0, 0.0, 0, 0, 0]             # first of equal maxima wins
+    want = oracle.postprocess(head, 416, 416)
+    got, n_kept, _ = eng16.postprocess(head, 416, 416)
+    assert n_kept == len(want) and det_fields_equal(got, want)
+    empty = np.zeros((4 + 4, 100), dtype=np.float32)
+    got, n_kept, n_cand = eng16.postprocess(empty, 416, 416, conf_thr=0.0)
+    assert n_kept == 0 and n_cand == 0                        # all-zero scores never pass (class stays -1)
+
+
+def test_postprocess_cap_overflow_reports_uncapped_count(eng16, oracle):
+    head = _rand_head(np.random.default_rng(12), 80, 3549, 0.2)
+    want = oracle.postprocess(head, 416, 416)
+    got, n_kept, _ = eng16.postprocess(head, 416, 416, cap=16)
+    assert n_kept == len(want) > 16 and len(got) == 16 and det_fields_equal(got, want[:16])
+
+
+# ---------------------------------------------------------------------------------------------------
+# forward pass
+# ---------------------------------------------------------------------------------------------------
+def test_forward_fp32_layers_and_head(eng32, oracle, ref_fp32):
+    frames = zm.synth_frames(2, 416, 416, seed=5, rects=False)
+    x = _pre(oracle, frames)
+    want = ref_fp32.forward(torch.from_numpy(x)).numpy()
+    got = eng32.forward(x)
+    for name in ("model.0", "model.2.cv2", "model.4.cv2", "model.9.cv2", "model.12.cv2", "model.15.cv2", "model.21.cv2",
+                 "model.22.cv2.0.2", "model.22.cv3.2.2"):
+        t = ref_fp32.taps[name][1].numpy()
+        g = eng32.tap(name, 1)
+        assert g.shape == t.shape, name
+        assert np.abs(g - t).max() <= 2e-4 * max(1.0, np.abs(t).max()), name
+    assert np.abs(got[:, :4] - want[:, :4]).max() <= FP32_BOX_TOL
+    assert np.abs(got[:, 4:] - want[:, 4:]).max() <= FP32_SCORE_TOL
+
+
+def test_forward_bf16_vs_emulating_oracle(eng16, oracle, ref_bf16):
+    frames = zm.synth_frames(2, 416, 416, seed=6, rects=False)
+    x = _pre(oracle, frames)
+    want = ref_bf16.forward(torch.from_numpy(x)).numpy()
+    got = eng16.forward(x)
+    assert np.abs(got[:, :4] - want[:, :4]).max() <= BF16E_BOX_TOL
+    assert np.abs(got[:, 4:] - want[:, 4:]).max() <= BF16E_SCORE_TOL
+
+
+def test_forward_bf16_vs_fp32_oracle(eng16, oracle, ref_fp32):
+    frames = np.concatenate([zm.synth_frames(2, 416, 416, seed=7, rects=False), zm.synth_frames(8, 416, 416, seed=1)[6:7]])
+    x = _pre(oracle, frames)
+    want = ref_fp32.forward(torch.from_numpy(x)).numpy()
+    got = eng16.forward(x)
+    assert np.abs(got[:, :4] - want[:, :4]).max() <= BF16_BOX_TOL
+    assert np.abs(got[:, 4:] - want[:, 4:]).max() <= BF16_SCORE_TOL
+
+
+# ---------------------------------------------------------------------------------------------------
+# whole path
+# ---------------------------------------------------------------------------------------------------
+def _match(got, want, iou_fn, min_iou=0.9):
+    used = set()
+    for g in got:
+        best, bj = 0.0, -1
+        for j, w_ in enumerate(want):
+            if j in used or w_["class_id"] != g["class_id"]:
+                continue
+            v = iou_fn([g["x"], g["y"], g["w"], g["h"]], [w_["x"], w_["y"], w_["w"], w_["h"]])
+            if v > best:
+                best, bj = v, j
+        if bj < 0 or best < min_iou:
+            return False
+        used.add(bj)
+    return True
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_detect_equals_oracle_postprocess_of_own_head(eng32, eng16, oracle, dtype):
+    """detect() == oracle post-processing applied to the engine's own head tensor, bit for bit:
+    pins preprocess -> forward -> decode -> NMS wiring without any NN tolerance."""
+    eng = eng32 if dtype == "fp32" else eng16
+    frames = list(zm.synth_frames(3, 416, 416, seed=5, rects=False)) + [zm.synth_frames(1, 800, 600, seed=3, rects=False)[0]]
+    for f in frames:
+        dets, n = eng.detect(f, cap=512)
+        want = oracle.postprocess(eng.head_tensor(0), f.shape[1], f.shape[0])
+        assert n == len(want) and det_fields_equal(dets, want[:512])
+        assert np.all(dets["track_id"] == 0) and (n == 0 or np.all(dets["timestamp"] > 1_600_000_000_000))
+
+
+def test_detect_fp32_matches_full_cpu_pipeline(eng32, oracle, ref_fp32):
+    """Whole path vs whole oracle (oracle preprocess -> fp32 reference forward -> oracle decode/NMS).
+    Candidates within 1e-3 of the confidence threshold or pairs within 1e-3 of the IoU threshold may
+    legitimately flip, so frames containing such cases are compared as matched sets."""
+    frames = zm.synth_frames(3, 416, 416, seed=5, rects=False)
+    x = _pre(oracle, frames)
+    heads = ref_fp32.forward(torch.from_numpy(x)).numpy()
+    for f, head in zip(frames, heads):
+        want = oracle.postprocess(head, 416, 416)
+        dets, n = eng32.detect(f, cap=512)
+        scores = head[4:].max(0)
+        near = np.any(np.abs(scores - 0.5) < 1e-3)
+        if not near and n == len(want):
+            assert np.array_equal(dets["class_id"], want["class_id"])
+            for k in ("x", "y", "w", "h"):
+                assert np.abs(dets[k] - want[k]).max() <= FP32_BOX_TOL / 416 * 2
+            assert np.abs(dets["confidence"] - want["confidence"]).max() <= FP32_SCORE_TOL
+        else:
+            assert abs(n - len(want)) <= 2 and _match(dets, want, oracle.iou, 0.5) or _match(want, dets, oracle.iou, 0.5)
+
+
+def test_detect_bf16_matches_cpu_pipeline_as_sets(eng16, oracle, ref_fp32):
+    """bf16 engine vs fp32 oracle: detections compared as sets (same class, IoU >= 0.9) after removing
+    oracle candidates inside the threshold-flip band |score - 0.5| < BF16_SCORE_TOL."""
+    frames = zm.synth_frames(2, 416, 416, seed=5, rects=False)
+    x = _pre(oracle, frames)
+    heads = ref_fp32.forward(torch.from_numpy(x)).numpy()
+    for f, head in zip(frames, heads):
+        dets, n = eng16.detect(f, cap=512)
+        sure = head.copy()
+        band = np.abs(sure[4:] - 0.5) < BF16_SCORE_TOL
+        sure[4:][band & (sure[4:] >= 0.5)] = 0.49                      # drop unsure candidates from the oracle side
+        want_sure = oracle.decode(sure, 416, 416)
+        # every confidently-above-threshold oracle candidate must be a GPU candidate too
+        gh = eng16.head_tensor(0)
+        gpu_cand = oracle.decode(gh, 416, 416)
+        assert _match(want_sure, gpu_cand, oracle.iou, 0.9)
+        assert n > 0
+
+
+def test_batch_equals_single_and_mixed_sizes(eng16):
+    frames = [zm.synth_frames(1, 416, 416, seed=21, rects=False)[0], zm.synth_frames(1, 800, 600, seed=22, rects=False)[0],
+              zm.synth_frames(1, 320, 240, seed=23)[0], zm.synth_frames(1, 416, 416, seed=24, rects=False)[0]]
+    singles = [eng16.detect(f, cap=512) for f in frames]
+    batch = eng16.detect_batch(frames, cap=512)
+    for (sd, sn), (bd, bn) in zip(singles, batch):
+        assert sn == bn and det_fields_equal(sd, bd)
+
+
+def test_device_path_slabs_equal_host_path(eng16):
+    frames = zm.synth_frames(8, 416, 416, seed=31, rects=False)
+    host = eng16.detect_batch(list(frames), cap=512)
+    d = torch.from_numpy(frames).cuda()
+    torch.cuda.synchronize()
+    eng16.detect_device(d.data_ptr(), 8, 416, 416, tag0=100)
+    slabs = eng16.read_slabs(8)
+    for i, ((hdr, dets), (hd, hn)) in enumerate(zip(slabs, host)):
+        assert hdr["n_kept"] == hn and hdr["frame_tag"] == 100 + i and det_fields_equal(dets, hd)
+
+
+def test_slab_overflow_flag(weights_path):
+    e = zly.Engine(weights_path, max_batch=1, max_dets=4, warmup_runs=0)
+    f = zm.synth_frames(1, 416, 416, seed=5, rects=False)[0]
+    dets, n = e.detect(f, cap=4)
+    d = torch.from_numpy(f[None]).cuda()
+    e.detect_device(d.data_ptr(), 1, 416, 416)
+    hdr, sd = e.read_slabs(1)[0]
+    assert n > 4 and len(dets) == 4 and hdr["n_kept"] == n and (hdr["flags"] & zly.SLAB_OVERFLOW)
+    e.close()
+
+
+def test_empty_frame_has_no_detections(eng16):
+    f = zm.synth_frames(8, 416, 416, seed=1)[0]          # a rect frame known to score below threshold everywhere
+    dets, n = eng16.detect(f)
+    assert n == 0 and len(dets) == 0
+
+
+def test_graph_and_eager_paths_agree(weights_path):
+    f = zm.synth_frames(2, 416, 416, seed=41, rects=False)
+    a = zly.Engine(weights_path, max_batch=2, max_dets=256, use_graph=True, warmup_runs=1)
+    b = zly.Engine(weights_path, max_batch=2, max_dets=256, use_graph=False, warmup_runs=0)
+    ra, rb = a.detect_batch(list(f), cap=256), b.detect_batch(list(f), cap=256)
+    for (da, na), (db, nb) in zip(ra, rb):
+        assert na == nb and det_fields_equal(da, db)
+    a.close(); b.close()
+
+
+def test_full_batch_64_is_batch_invariant(weights_path):
+    """BASELINE config 3 size (batch 64): every frame's slab equals its single-frame result."""
+    e = zly.Engine(weights_path, max_batch=64, max_dets=128, warmup_runs=1)
+    frames = zm.synth_frames(64, 416, 416, seed=77, rects=False)
+    d = torch.from_numpy(frames).cuda()
+    e.detect_device(d.data_ptr(), 64, 416, 416)
+    slabs = e.read_slabs(64)
+    perm = np.random.default_rng(0).permutation(64)
+    d2 = torch.from_numpy(frames[perm]).cuda()
+    e.detect_device(d2.data_ptr(), 64, 416, 416)
+    slabs2 = e.read_slabs(64)
+    for i in range(64):
+        assert det_fields_equal(slabs2[i][1], slabs[perm[i]][1])      # permutation equivariance
+    for i in (0, 17, 63):
+        dets, n = e.detect(frames[i], cap=128)
+        assert slabs[i][0]["n_kept"] == n and det_fields_equal(slabs[i][1], dets)
+    e.close()
+
+
+def test_model_file_errors(weights_path, tmp_path):
+    with pytest.raises(zly.ZlyError) as ei:
+        zly.Engine(str(tmp_path / "missing.zlyw"))
+    assert ei.value.code == zly.ERR_MODEL_NOT_FOUND
+    bad = tmp_path / "bad.zlyw"
+    bad.write_bytes(b"ONNX MODEL PLACEHOLDER")          # what reference start.sh:136-144 writes on export failure
+    with pytest.raises(zly.ZlyError) as ei:
+        zly.Engine(str(bad))
+    assert ei.value.code == zly.ERR_MODEL_LOAD

@@ -1,0 +1,857 @@
+// engine.cpp -- the detect engine behind the C ABI of include/zly.h: model plan, HBM layout,
+// stream/graph orchestration.  Compiled with hipcc; the kernels live in kernels_*.hip.
+//
+// Path (reference OnnxInferenceEngine::runInference, src/inference/onnx_engine.cpp:518-646):
+//   preprocess -> YOLOv8 forward (63 convs as 60 MFMA launches, SPPF pools, 2 upsamples, 3 head
+//   decodes) -> decode+threshold -> class-aware NMS -> fixed-size result slab per frame.
+//
+// HBM layout: every activation is NHWC, batch-major, in the engine dtype (bf16 or fp32).  Concat
+// and C2f's split never move data: producers write into channel slices of the consumer's concat
+// buffer (ConvArgs::out_cs/out_co) and consumers read channel slices (in_cs/in_co).
+#include "zly_internal.h"
+#include "weights.h"
+
+#include <algorithm>
+#include <chrono>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+#include <string.h>
+#include <stdio.h>
+
+namespace zly {
+
+static thread_local std::string g_last_error;
+
+static int fail(int code, const std::string& msg) { g_last_error = msg; return code; }
+
+#define HIP_TRY(expr, code)                                                                        \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess)                                                                      \
+            return fail((code), std::string(#expr) + ": " + hipGetErrorString(_e));                \
+    } while (0)
+
+struct View { int buf; int co; int C; };
+
+struct Buffer {
+    std::string name;
+    int H = 0, W = 0, C = 0;
+    bool f32 = false;          // always fp32 (final Detect logits) regardless of engine dtype
+    void* ptr = nullptr;
+    size_t elems_per_frame() const { return (size_t)H * W * C; }
+};
+
+enum OpKind { OP_PREPROCESS = 0, OP_CONV = 1, OP_SPPF = 2, OP_UPSAMPLE = 3, OP_HEAD = 4, OP_DECODE = 5, OP_NMS = 6 };
+
+struct Op {
+    int kind = 0;
+    std::string name;
+    // conv
+    View in{-1, 0, 0}, out{-1, 0, 0}, res{-1, 0, 0};
+    int ks = 1, stride = 1, act = 0, out_f32 = 0;
+    int cout = 0, cout_pad = 0, nk = 0, K = 0;
+    size_t w_off = 0, b_off = 0;       // offsets into the device weight blob
+    std::vector<std::string> taps;     // conv names whose outputs this op produces (for zly_debug_tap)
+    std::vector<int> tap_co;           // channel offset of each tap inside `out`
+    std::vector<int> tap_c;
+    // sppf / upsample / head
+    int c = 0;                         // sppf: hidden width; upsample: channels
+    int level = 0, stride_px = 0, anchor_off = 0;
+    double flops = 0, bytes = 0;
+};
+
+}  // namespace zly
+
+using namespace zly;
+
+struct zly_engine {
+    zly_config cfg;
+    std::string weights_path;
+    int dev = 0;
+    int dtype = ZLY_DTYPE_BF16;
+    size_t esz = 2;
+    ModelFile model;
+    int nc = 0, N = 0;
+    int lvl_h[3], lvl_w[3];
+    std::vector<Buffer> bufs;
+    std::vector<Op> ops;
+    int in_buf = -1;
+    std::map<std::string, std::pair<int, int>> tap_index;   // conv name -> (op index, tap slot)
+
+    void* d_weights = nullptr;
+    float* d_head = nullptr;          // [max_batch][4+nc][N]
+    Cand* d_cand = nullptr;           // [max_batch][N]
+    Cand* d_scratch = nullptr;        // [max_batch][N]  (NMS spill when a frame has > 1024 candidates)
+    int* d_count = nullptr;           // [max_batch]
+    unsigned char* d_slabs = nullptr; // [max_batch][slab_bytes]
+    FrameDesc* d_desc = nullptr;      // [max_batch]
+    FrameDesc* h_desc = nullptr;      // pinned
+    std::vector<FrameDesc> desc_cache;
+    uint8_t* d_stage = nullptr;       // frame staging (host path)
+    uint8_t* h_stage = nullptr;       // pinned
+    size_t stage_bytes = 0;
+    unsigned char* h_slabs = nullptr; // pinned
+    float* d_scratch_f32 = nullptr;   // stage-level entry points
+    size_t scratch_f32_elems = 0;
+
+    hipStream_t stream = nullptr;
+    std::map<int, hipGraphExec_t> graphs;   // batch size -> captured forward+decode
+    int last_n = 0;
+
+    std::mutex mu;
+    zly_stats stats{};
+};
+
+namespace zly {
+
+static size_t slab_bytes_of(const zly_engine* e) { return sizeof(zly_slab_header) + (size_t)e->cfg.max_dets * sizeof(zly_det); }
+
+// ------------------------------------------------------------------------------------------------
+// plan
+// ------------------------------------------------------------------------------------------------
+struct PlanBuilder {
+    zly_engine* e;
+    std::vector<uint8_t> blob;         // host image of the device weight blob
+    std::string err;
+    int kstep;
+
+    int add_buffer(const std::string& name, int H, int W, int C, bool f32 = false) {
+        Buffer b;
+        b.name = name; b.H = H; b.W = W; b.C = C; b.f32 = f32;
+        e->bufs.push_back(b);
+        return (int)e->bufs.size() - 1;
+    }
+    size_t append(const void* p, size_t bytes) {
+        size_t off = (blob.size() + 255) / 256 * 256;
+        blob.resize(off + bytes);
+        memcpy(blob.data() + off, p, bytes);
+        return off;
+    }
+    bool conv(const std::vector<std::string>& names, View in, View out, View res = View{-1, 0, 0}, bool out_f32 = false) {
+        std::vector<const ConvRec*> srcs;
+        for (const std::string& n : names) {
+            const ConvRec* r = e->model.find(n);
+            if (!r) { err = "conv missing from model file: " + n; return false; }
+            srcs.push_back(r);
+        }
+        const ConvRec* r0 = srcs[0];
+        for (const ConvRec* r : srcs)
+            if (r->cin != r0->cin || r->k != r0->k || r->stride != r0->stride || r->act != r0->act) { err = "cannot fuse " + names[0]; return false; }
+        const Buffer& ib = e->bufs[(size_t)in.buf];
+        const Buffer& ob = e->bufs[(size_t)out.buf];
+        const int epl = e->dtype == ZLY_DTYPE_BF16 ? 8 : 4;
+        if (in.C < r0->cin || in.C % epl != 0 || in.co % epl != 0 || ib.C % epl != 0 || in.co + in.C > ib.C) { err = "bad input view for " + names[0]; return false; }
+        Op op;
+        op.kind = OP_CONV;
+        op.name = names[0];
+        for (size_t i = 1; i < names.size(); ++i) op.name += "+" + names[i];
+        if (op.name.size() > 47) op.name.resize(47);
+        op.in = in; op.out = out; op.res = res;
+        op.ks = r0->k; op.stride = r0->stride; op.act = r0->act; op.out_f32 = out_f32 ? 1 : 0;
+        std::vector<uint8_t> w;
+        std::vector<float> b;
+        repack_conv(srcs, in.C, kstep, e->dtype == ZLY_DTYPE_BF16, &w, &b, &op.cout, &op.cout_pad, &op.nk);
+        if (out.C != op.cout || out.co % 4 != 0 || ob.C % 4 != 0 || out.co + out.C > ob.C) { err = "bad output view for " + names[0]; return false; }
+        if (out_f32 != ob.f32) { err = "output dtype mismatch for " + names[0]; return false; }
+        const int Ho = ob.H, Wo = ob.W;
+        if (Ho != (ib.H + 2 * (op.ks / 2) - op.ks) / op.stride + 1 || Wo != (ib.W + 2 * (op.ks / 2) - op.ks) / op.stride + 1) { err = "spatial mismatch for " + names[0]; return false; }
+        op.K = op.ks * op.ks * in.C;
+        op.w_off = append(w.data(), w.size());
+        op.b_off = append(b.data(), b.size() * sizeof(float));
+        int co = 0;
+        double macs = 0;
+        for (size_t i = 0; i < srcs.size(); ++i) {
+            op.taps.push_back(names[i]); op.tap_co.push_back(co); op.tap_c.push_back(srcs[i]->cout);
+            co += srcs[i]->cout;
+            macs += (double)Ho * Wo * srcs[i]->cout * srcs[i]->cin * op.ks * op.ks;
+        }
+        op.flops = 2.0 * macs;
+        const double osz = out_f32 ? 4.0 : (double)e->esz;
+        op.bytes = (double)ib.H * ib.W * r0->cin * e->esz + (double)Ho * Wo * op.cout * osz +
+                   (double)op.cout * r0->cin * op.ks * op.ks * e->esz + (res.buf >= 0 ? (double)Ho * Wo * op.cout * e->esz : 0.0);
+        e->ops.push_back(op);
+        for (size_t i = 0; i < names.size(); ++i) e->tap_index[names[i]] = std::make_pair((int)e->ops.size() - 1, (int)i);
+        return true;
+    }
+    // C2f(c1 -> c2, n bottlenecks): cv1 writes [0,2c) of the concat buffer, bottleneck i reads
+    // [(1+i)c,(2+i)c) and writes [(2+i)c,(3+i)c), cv2 reads all (2+n)c channels.
+    bool c2f(const std::string& p, View in, View out, int n, bool shortcut, int H, int W) {
+        const int c = out.C / 2;
+        const int cat = add_buffer(p + ".cat", H, W, (2 + n) * c);
+        const int tmp = add_buffer(p + ".tmp", H, W, c);
+        if (!conv({p + ".cv1"}, in, View{cat, 0, 2 * c})) return false;
+        for (int i = 0; i < n; ++i) {
+            const View src{cat, (1 + i) * c, c};
+            const std::string m = p + ".m." + std::to_string(i);
+            if (!conv({m + ".cv1"}, src, View{tmp, 0, c})) return false;
+            if (!conv({m + ".cv2"}, View{tmp, 0, c}, View{cat, (2 + i) * c, c}, shortcut ? src : View{-1, 0, 0})) return false;
+        }
+        return conv({p + ".cv2"}, View{cat, 0, (2 + n) * c}, out);
+    }
+};
+
+static int build_plan(zly_engine* e, std::string* err)
+{
+    PlanBuilder pb;
+    pb.e = e;
+    pb.kstep = conv_kstep(e->dtype);
+    const ModelFile& m = e->model;
+    const int W = e->cfg.model_w, H = e->cfg.model_h;
+    const int* ch = m.ch;
+    const int* nb = m.n_c2f;
+    if (m.reg_max != 16) { *err = "only reg_max = 16 is supported"; return ZLY_ERR_MODEL_LOAD; }
+    for (int i = 0; i < 5; ++i)
+        if (ch[i] % 16 != 0) { *err = "channel widths must be multiples of 16"; return ZLY_ERR_MODEL_LOAD; }
+    const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, H8 = H / 8, W8 = W / 8, H16 = H / 16, W16 = W / 16, H32 = H / 32, W32 = W / 32;
+
+    e->in_buf = pb.add_buffer("images", H, W, 8);
+    const int a0 = pb.add_buffer("model.0", H2, W2, ch[0]);
+    const int a1 = pb.add_buffer("model.1", H4, W4, ch[1]);
+    const int a2 = pb.add_buffer("model.2", H4, W4, ch[1]);
+    const int a3 = pb.add_buffer("model.3", H8, W8, ch[2]);
+    const int cat14 = pb.add_buffer("cat14[up(12),4]", H8, W8, ch[3] + ch[2]);
+    const int a5 = pb.add_buffer("model.5", H16, W16, ch[3]);
+    const int cat11 = pb.add_buffer("cat11[up(9),6]", H16, W16, ch[4] + ch[3]);
+    const int a7 = pb.add_buffer("model.7", H32, W32, ch[4]);
+    const int a8 = pb.add_buffer("model.8", H32, W32, ch[4]);
+    const int spp = pb.add_buffer("model.9.cat", H32, W32, 2 * ch[4]);
+    const int cat20 = pb.add_buffer("cat20[19,9]", H32, W32, ch[3] + ch[4]);
+    const int cat17 = pb.add_buffer("cat17[16,12]", H16, W16, ch[2] + ch[3]);
+    const int a15 = pb.add_buffer("model.15", H8, W8, ch[2]);
+    const int a18 = pb.add_buffer("model.18", H16, W16, ch[3]);
+    const int a21 = pb.add_buffer("model.21", H32, W32, ch[4]);
+
+    Op pre; pre.kind = OP_PREPROCESS; pre.name = "preprocess";
+    pre.bytes = (double)W * H * 3 + (double)W * H * 8 * e->esz;
+    e->ops.push_back(pre);
+
+    bool ok = true;
+    ok = ok && pb.conv({"model.0"}, View{e->in_buf, 0, 8}, View{a0, 0, ch[0]});
+    ok = ok && pb.conv({"model.1"}, View{a0, 0, ch[0]}, View{a1, 0, ch[1]});
+    ok = ok && pb.c2f("model.2", View{a1, 0, ch[1]}, View{a2, 0, ch[1]}, nb[0], true, H4, W4);
+    ok = ok && pb.conv({"model.3"}, View{a2, 0, ch[1]}, View{a3, 0, ch[2]});
+    ok = ok && pb.c2f("model.4", View{a3, 0, ch[2]}, View{cat14, ch[3], ch[2]}, nb[1], true, H8, W8);          // P3 -> cat14
+    ok = ok && pb.conv({"model.5"}, View{cat14, ch[3], ch[2]}, View{a5, 0, ch[3]});
+    ok = ok && pb.c2f("model.6", View{a5, 0, ch[3]}, View{cat11, ch[4], ch[3]}, nb[2], true, H16, W16);        // P4 -> cat11
+    ok = ok && pb.conv({"model.7"}, View{cat11, ch[4], ch[3]}, View{a7, 0, ch[4]});
+    ok = ok && pb.c2f("model.8", View{a7, 0, ch[4]}, View{a8, 0, ch[4]}, nb[3], true, H32, W32);
+    // SPPF
+    ok = ok && pb.conv({"model.9.cv1"}, View{a8, 0, ch[4]}, View{spp, 0, ch[4] / 2});
+    if (ok) {
+        Op p; p.kind = OP_SPPF; p.name = "model.9.pool"; p.in = View{spp, 0, ch[4] / 2}; p.c = ch[4] / 2;
+        p.bytes = (double)H32 * W32 * (ch[4] / 2) * 4 * e->esz;
+        e->ops.push_back(p);
+    }
+    ok = ok && pb.conv({"model.9.cv2"}, View{spp, 0, 2 * ch[4]}, View{cat20, ch[3], ch[4]});                     // P5 -> cat20
+    // neck, top-down
+    if (ok) {
+        Op u; u.kind = OP_UPSAMPLE; u.name = "model.10.upsample"; u.in = View{cat20, ch[3], ch[4]}; u.out = View{cat11, 0, ch[4]}; u.c = ch[4];
+        u.bytes = (double)H32 * W32 * ch[4] * e->esz * 5;
+        e->ops.push_back(u);
+    }
+    ok = ok && pb.c2f("model.12", View{cat11, 0, ch[4] + ch[3]}, View{cat17, ch[2], ch[3]}, nb[4], false, H16, W16);
+    if (ok) {
+        Op u; u.kind = OP_UPSAMPLE; u.name = "model.13.upsample"; u.in = View{cat17, ch[2], ch[3]}; u.out = View{cat14, 0, ch[3]}; u.c = ch[3];
+        u.bytes = (double)H16 * W16 * ch[3] * e->esz * 5;
+        e->ops.push_back(u);
+    }
+    ok = ok && pb.c2f("model.15", View{cat14, 0, ch[3] + ch[2]}, View{a15, 0, ch[2]}, nb[5], false, H8, W8);
+    // neck, bottom-up
+    ok = ok && pb.conv({"model.16"}, View{a15, 0, ch[2]}, View{cat17, 0, ch[2]});
+    ok = ok && pb.c2f("model.18", View{cat17, 0, ch[2] + ch[3]}, View{a18, 0, ch[3]}, nb[6], false, H16, W16);
+    ok = ok && pb.conv({"model.19"}, View{a18, 0, ch[3]}, View{cat20, 0, ch[3]});
+    ok = ok && pb.c2f("model.21", View{cat20, 0, ch[3] + ch[4]}, View{a21, 0, ch[4]}, nb[7], false, H32, W32);
+    // Detect: per level, the two branches' first 3x3 convs read the same tensor and are one launch
+    const int c2 = std::max(16, std::max(ch[2] / 4, 4 * m.reg_max));
+    const int c3 = std::max(ch[2], std::min(m.nc, 100));
+    const int feats[3] = {a15, a18, a21};
+    const int fch[3] = {ch[2], ch[3], ch[4]};
+    const int fh[3] = {H8, H16, H32}, fw[3] = {W8, W16, W32};
+    const int ncp = (m.nc + 3) / 4 * 4;
+    int anchor_off = 0;
+    e->N = fh[0] * fw[0] + fh[1] * fw[1] + fh[2] * fw[2];
+    for (int l = 0; l < 3 && ok; ++l) {
+        const std::string L = std::to_string(l);
+        const int hd1 = pb.add_buffer("detect." + L + ".stem", fh[l], fw[l], c2 + c3);
+        const int hb2 = pb.add_buffer("detect." + L + ".box2", fh[l], fw[l], c2);
+        const int hc2 = pb.add_buffer("detect." + L + ".cls2", fh[l], fw[l], c3);
+        const int hout = pb.add_buffer("detect." + L + ".logits", fh[l], fw[l], 64 + ncp, true);
+        ok = ok && pb.conv({"model.22.cv2." + L + ".0", "model.22.cv3." + L + ".0"}, View{feats[l], 0, fch[l]}, View{hd1, 0, c2 + c3});
+        ok = ok && pb.conv({"model.22.cv2." + L + ".1"}, View{hd1, 0, c2}, View{hb2, 0, c2});
+        ok = ok && pb.conv({"model.22.cv3." + L + ".1"}, View{hd1, c2, c3}, View{hc2, 0, c3});
+        ok = ok && pb.conv({"model.22.cv2." + L + ".2"}, View{hb2, 0, c2}, View{hout, 0, 64}, View{-1, 0, 0}, true);
+        ok = ok && pb.conv({"model.22.cv3." + L + ".2"}, View{hc2, 0, c3}, View{hout, 64, m.nc}, View{-1, 0, 0}, true);
+        if (ok) {
+            Op h; h.kind = OP_HEAD; h.name = "detect." + L + ".decode"; h.in = View{hout, 0, 64 + ncp};
+            h.level = l; h.stride_px = 8 << l; h.anchor_off = anchor_off;
+            h.bytes = (double)fh[l] * fw[l] * ((64 + m.nc) * 4.0 + (4 + m.nc) * 4.0);
+            e->ops.push_back(h);
+        }
+        e->lvl_h[l] = fh[l]; e->lvl_w[l] = fw[l];
+        anchor_off += fh[l] * fw[l];
+    }
+    if (!ok) { *err = pb.err; return ZLY_ERR_MODEL_LOAD; }
+    Op d; d.kind = OP_DECODE; d.name = "decode+threshold"; d.bytes = (double)(4 + m.nc) * e->N * 4; e->ops.push_back(d);
+    Op nm; nm.kind = OP_NMS; nm.name = "nms"; e->ops.push_back(nm);
+
+    // device allocations
+    const int B = e->cfg.max_batch;
+    for (Buffer& b : e->bufs) {
+        const size_t bytes = b.elems_per_frame() * (b.f32 ? 4 : e->esz) * (size_t)B;
+        if (hipMalloc(&b.ptr, bytes) != hipSuccess) { *err = "hipMalloc failed for " + b.name; return ZLY_ERR_SYSTEM; }
+        hipMemset(b.ptr, 0, bytes);
+    }
+    if (hipMalloc(&e->d_weights, pb.blob.size()) != hipSuccess) { *err = "hipMalloc failed for weights"; return ZLY_ERR_SYSTEM; }
+    if (hipMemcpy(e->d_weights, pb.blob.data(), pb.blob.size(), hipMemcpyHostToDevice) != hipSuccess) { *err = "weight upload failed"; return ZLY_ERR_SYSTEM; }
+    return ZLY_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// execution
+// ------------------------------------------------------------------------------------------------
+static hipError_t run_op(zly_engine* e, const Op& op, int n, const uint8_t* d_src, void* d_slabs_out, uint32_t tag0, hipStream_t s)
+{
+    switch (op.kind) {
+    case OP_PREPROCESS:
+        return launch_preprocess(e->dtype, d_src, e->d_desc, n, e->bufs[(size_t)e->in_buf].ptr, nullptr, e->cfg.model_w, e->cfg.model_h, s);
+    case OP_CONV: {
+        const Buffer& ib = e->bufs[(size_t)op.in.buf];
+        const Buffer& ob = e->bufs[(size_t)op.out.buf];
+        ConvArgs a;
+        a.in = ib.ptr; a.in_cs = ib.C; a.in_co = op.in.co;
+        a.H = ib.H; a.W = ib.W; a.Cin = op.in.C;
+        a.wgt = (const char*)e->d_weights + op.w_off;
+        a.bias = (const float*)((const char*)e->d_weights + op.b_off);
+        a.out = ob.ptr; a.out_cs = ob.C; a.out_co = op.out.co;
+        a.Ho = ob.H; a.Wo = ob.W; a.Cout = op.cout;
+        if (op.res.buf >= 0) { const Buffer& rb = e->bufs[(size_t)op.res.buf]; a.res = rb.ptr; a.res_cs = rb.C; a.res_co = op.res.co; }
+        else { a.res = nullptr; a.res_cs = 0; a.res_co = 0; }
+        a.stride = op.stride; a.pad = op.ks / 2;
+        a.K = op.K; a.nk = op.nk; a.M = n * ob.H * ob.W; a.act = op.act; a.out_f32 = op.out_f32;
+        ConvLaunch cfg;
+        conv_pick_config(e->dtype, op.ks, op.in.C, op.cout_pad, a.M, &cfg);
+        return launch_conv(e->dtype, a, cfg, s);
+    }
+    case OP_SPPF: {
+        const Buffer& b = e->bufs[(size_t)op.in.buf];
+        return launch_sppf_pool(e->dtype, b.ptr, b.C, op.c, n, b.H, b.W, s);
+    }
+    case OP_UPSAMPLE: {
+        const Buffer& ib = e->bufs[(size_t)op.in.buf];
+        const Buffer& ob = e->bufs[(size_t)op.out.buf];
+        return launch_upsample2x(e->dtype, ib.ptr, ib.C, op.in.co, ob.ptr, ob.C, op.out.co, op.c, n, ib.H, ib.W, s);
+    }
+    case OP_HEAD: {
+        const Buffer& b = e->bufs[(size_t)op.in.buf];
+        return launch_head((const float*)b.ptr, b.C, e->nc, n, b.H, b.W, op.stride_px, e->d_head, e->N, op.anchor_off, s);
+    }
+    case OP_DECODE: {
+        hipError_t r = hipMemsetAsync(e->d_count, 0, sizeof(int) * (size_t)n, s);
+        if (r != hipSuccess) return r;
+        return launch_decode(e->d_head, e->nc, e->N, n, e->d_desc, e->cfg.conf_thr, e->d_cand, e->d_count, s);
+    }
+    case OP_NMS:
+        return launch_nms(e->d_cand, e->d_count, e->N, n, e->cfg.iou_thr, e->nc, e->d_scratch,
+                          d_slabs_out ? d_slabs_out : e->d_slabs, e->cfg.max_dets, tag0, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+// ops [first, last) -- the graph-capturable middle of the path is [1, ops.size()-1)
+static hipError_t run_ops(zly_engine* e, size_t first, size_t last, int n, const uint8_t* d_src, void* d_slabs_out, uint32_t tag0, hipStream_t s)
+{
+    for (size_t i = first; i < last; ++i) {
+        hipError_t r = run_op(e, e->ops[i], n, d_src, d_slabs_out, tag0, s);
+        if (r != hipSuccess) return r;
+    }
+    return hipSuccess;
+}
+
+static int run_path(zly_engine* e, int n, const uint8_t* d_src, void* d_slabs_out, uint32_t tag0, hipStream_t s, bool with_pre)
+{
+    const size_t nops = e->ops.size();
+    if (with_pre) HIP_TRY(run_op(e, e->ops[0], n, d_src, nullptr, 0, s), ZLY_ERR_INFERENCE);
+    if (e->cfg.use_graph) {
+        auto it = e->graphs.find(n);
+        if (it == e->graphs.end()) {
+            // capture on the engine's own stream, then replay on whichever stream the caller uses
+            hipGraph_t g = nullptr;
+            hipGraphExec_t ge = nullptr;
+            HIP_TRY(hipStreamSynchronize(s), ZLY_ERR_INFERENCE);
+            HIP_TRY(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal), ZLY_ERR_INFERENCE);
+            hipError_t r = run_ops(e, 1, nops - 1, n, nullptr, nullptr, 0, e->stream);
+            hipError_t r2 = hipStreamEndCapture(e->stream, &g);
+            if (r != hipSuccess || r2 != hipSuccess) return fail(ZLY_ERR_INFERENCE, std::string("graph capture failed: ") + hipGetErrorString(r != hipSuccess ? r : r2));
+            HIP_TRY(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0), ZLY_ERR_INFERENCE);
+            hipGraphDestroy(g);
+            it = e->graphs.emplace(n, ge).first;
+        }
+        HIP_TRY(hipGraphLaunch(it->second, s), ZLY_ERR_INFERENCE);
+    } else {
+        HIP_TRY(run_ops(e, 1, nops - 1, n, nullptr, nullptr, 0, s), ZLY_ERR_INFERENCE);
+    }
+    HIP_TRY(run_op(e, e->ops[nops - 1], n, nullptr, d_slabs_out, tag0, s), ZLY_ERR_INFERENCE);
+    e->last_n = n;
+    return ZLY_OK;
+}
+
+static int set_desc(zly_engine* e, int n, const int32_t* w, const int32_t* h, const size_t* offs, hipStream_t s)
+{
+    bool same = (int)e->desc_cache.size() >= n;
+    for (int i = 0; i < n && same; ++i)
+        same = e->desc_cache[(size_t)i].w == w[i] && e->desc_cache[(size_t)i].h == h[i] && e->desc_cache[(size_t)i].src_off == offs[i];
+    if (same) return ZLY_OK;
+    // the pinned mirror may still be in flight from the previous call on another stream
+    HIP_TRY(hipStreamSynchronize(e->stream), ZLY_ERR_INFERENCE);
+    if ((int)e->desc_cache.size() < n) e->desc_cache.resize((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        FrameDesc d; d.src_off = offs[i]; d.w = w[i]; d.h = h[i];
+        e->h_desc[i] = d;
+        e->desc_cache[(size_t)i] = d;
+    }
+    for (size_t i = (size_t)n; i < e->desc_cache.size(); ++i) e->desc_cache[i].w = -1;
+    HIP_TRY(hipMemcpyAsync(e->d_desc, e->h_desc, sizeof(FrameDesc) * (size_t)n, hipMemcpyHostToDevice, s), ZLY_ERR_INFERENCE);
+    return ZLY_OK;
+}
+
+static int ensure_stage(zly_engine* e, size_t bytes)
+{
+    if (bytes <= e->stage_bytes) return ZLY_OK;
+    HIP_TRY(hipStreamSynchronize(e->stream), ZLY_ERR_SYSTEM);
+    if (e->d_stage) hipFree(e->d_stage);
+    if (e->h_stage) hipHostFree(e->h_stage);
+    e->d_stage = nullptr; e->h_stage = nullptr; e->stage_bytes = 0;
+    const size_t cap = (bytes + (1u << 20) - 1) / (1u << 20) * (1u << 20);
+    HIP_TRY(hipMalloc((void**)&e->d_stage, cap), ZLY_ERR_SYSTEM);
+    HIP_TRY(hipHostMalloc((void**)&e->h_stage, cap, hipHostMallocDefault), ZLY_ERR_SYSTEM);
+    e->stage_bytes = cap;
+    return ZLY_OK;
+}
+
+static int ensure_scratch_f32(zly_engine* e, size_t elems)
+{
+    if (elems <= e->scratch_f32_elems) return ZLY_OK;
+    HIP_TRY(hipStreamSynchronize(e->stream), ZLY_ERR_SYSTEM);
+    if (e->d_scratch_f32) hipFree(e->d_scratch_f32);
+    e->d_scratch_f32 = nullptr; e->scratch_f32_elems = 0;
+    HIP_TRY(hipMalloc((void**)&e->d_scratch_f32, elems * sizeof(float)), ZLY_ERR_SYSTEM);
+    e->scratch_f32_elems = elems;
+    return ZLY_OK;
+}
+
+static uint64_t now_ms()
+{
+    return (uint64_t)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::system_clock::now().time_since_epoch()).count();
+}
+
+static void destroy_engine(zly_engine* e)
+{
+    if (!e) return;
+    hipSetDevice(e->dev);
+    if (e->stream) hipStreamSynchronize(e->stream);
+    for (auto& kv : e->graphs) hipGraphExecDestroy(kv.second);
+    for (Buffer& b : e->bufs) if (b.ptr) hipFree(b.ptr);
+    void* dptrs[] = {e->d_weights, e->d_head, e->d_cand, e->d_scratch, e->d_count, e->d_slabs, e->d_desc, e->d_stage, e->d_scratch_f32};
+    for (void* p : dptrs) if (p) hipFree(p);
+    if (e->h_desc) hipHostFree(e->h_desc);
+    if (e->h_stage) hipHostFree(e->h_stage);
+    if (e->h_slabs) hipHostFree(e->h_slabs);
+    if (e->stream) hipStreamDestroy(e->stream);
+    delete e;
+}
+
+}  // namespace zly
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+const char* zly_last_error(void) { return g_last_error.c_str(); }
+const char* zly_version(void) { return "zly-hip 0.1 (gfx950)"; }
+
+void zly_default_config(zly_config* c)
+{
+    memset(c, 0, sizeof *c);
+    c->weights_path = nullptr;
+    c->model_w = 416; c->model_h = 416;          // configs/server.json:30-31
+    c->conf_thr = 0.5f; c->iou_thr = 0.45f;      // configs/server.json:7-8
+    c->max_batch = 1; c->max_dets = 64; c->device = 0;
+    c->dtype = ZLY_DTYPE_BF16; c->warmup_runs = 3; c->use_graph = 1;
+}
+
+int32_t zly_create(const zly_config* cfg, zly_engine** out)
+{
+    if (!cfg || !out) return fail(ZLY_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    if (cfg->model_w <= 0 || cfg->model_h <= 0 || cfg->model_w % 32 || cfg->model_h % 32)
+        return fail(ZLY_ERR_INVALID_ARGUMENT, "model_w/model_h must be positive multiples of 32");
+    if (cfg->max_batch < 1 || cfg->max_dets < 1) return fail(ZLY_ERR_INVALID_ARGUMENT, "max_batch/max_dets must be >= 1");
+    if (cfg->dtype != ZLY_DTYPE_BF16 && cfg->dtype != ZLY_DTYPE_FP32) return fail(ZLY_ERR_INVALID_ARGUMENT, "dtype must be ZLY_DTYPE_FP32 or ZLY_DTYPE_BF16");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(ZLY_ERR_SYSTEM, "no HIP device available: this engine has no CPU fallback");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(ZLY_ERR_INVALID_ARGUMENT, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(cfg->device), ZLY_ERR_SYSTEM);
+
+    zly_engine* e = new zly_engine();
+    e->cfg = *cfg;
+    e->weights_path = cfg->weights_path ? cfg->weights_path : "";
+    e->cfg.weights_path = nullptr;
+    e->dev = cfg->device;
+    e->dtype = cfg->dtype;
+    e->esz = cfg->dtype == ZLY_DTYPE_BF16 ? 2 : 4;
+    std::string err;
+    int rc = load_zlyw(e->weights_path.c_str(), &e->model, &err);
+    if (rc != ZLY_OK) { destroy_engine(e); return fail(rc, err); }
+    e->nc = e->model.nc;
+    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { destroy_engine(e); return fail(ZLY_ERR_SYSTEM, "hipStreamCreate failed"); }
+    rc = build_plan(e, &err);
+    if (rc != ZLY_OK) { destroy_engine(e); return fail(rc, err); }
+
+    const size_t B = (size_t)cfg->max_batch, N = (size_t)e->N;
+    bool ok = true;
+    ok = ok && hipMalloc((void**)&e->d_head, B * (4 + (size_t)e->nc) * N * sizeof(float)) == hipSuccess;
+    ok = ok && hipMalloc((void**)&e->d_cand, B * N * sizeof(Cand)) == hipSuccess;
+    ok = ok && hipMalloc((void**)&e->d_scratch, B * N * sizeof(Cand)) == hipSuccess;
+    ok = ok && hipMalloc((void**)&e->d_count, B * sizeof(int)) == hipSuccess;
+    ok = ok && hipMalloc((void**)&e->d_slabs, B * slab_bytes_of(e)) == hipSuccess;
+    ok = ok && hipMalloc((void**)&e->d_desc, B * sizeof(FrameDesc)) == hipSuccess;
+    ok = ok && hipHostMalloc((void**)&e->h_desc, B * sizeof(FrameDesc), hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipHostMalloc((void**)&e->h_slabs, B * slab_bytes_of(e), hipHostMallocDefault) == hipSuccess;
+    if (!ok) { destroy_engine(e); return fail(ZLY_ERR_SYSTEM, "device allocation failed"); }
+    hipMemset(e->d_slabs, 0, B * slab_bytes_of(e));
+    hipMemset(e->d_count, 0, B * sizeof(int));
+
+    // warmupModel analogue (onnx_engine.cpp:919-954): constant-128 frames of model size
+    if (cfg->warmup_runs > 0) {
+        const size_t fb = (size_t)cfg->model_w * cfg->model_h * 3;
+        std::vector<uint8_t> grey(fb, 128);
+        std::vector<zly_det> dets((size_t)cfg->max_dets);
+        for (int i = 0; i < cfg->warmup_runs; ++i) {
+            int32_t nd = 0;
+            rc = zly_detect(e, grey.data(), fb, cfg->model_w, cfg->model_h, dets.data(), cfg->max_dets, &nd);
+            if (rc != ZLY_OK) { std::string m = g_last_error; destroy_engine(e); return fail(rc, "warm-up failed: " + m); }
+        }
+        e->stats = zly_stats{};
+    }
+    *out = e;
+    return ZLY_OK;
+}
+
+int32_t zly_destroy(zly_engine* e)
+{
+    if (!e) return ZLY_OK;
+    destroy_engine(e);
+    return ZLY_OK;
+}
+
+static int detect_host_locked(zly_engine* e, int32_t n, const uint8_t* const* bgr, const size_t* nbytes,
+                              const int32_t* w, const int32_t* h, zly_det* out, int32_t cap, int32_t* n_out)
+{
+    HIP_TRY(hipSetDevice(e->dev), ZLY_ERR_SYSTEM);
+    std::vector<size_t> offs((size_t)n);
+    size_t total = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!bgr[i] || w[i] <= 0 || h[i] <= 0 || nbytes[i] != (size_t)w[i] * (size_t)h[i] * 3u) {
+            e->stats.inference_errors++;
+            return fail(ZLY_ERR_INVALID_INPUT, "Invalid image data size: expected " + std::to_string((size_t)(w[i] > 0 ? w[i] : 0) * (size_t)(h[i] > 0 ? h[i] : 0) * 3u) +
+                                                   ", got " + std::to_string(nbytes[i]));
+        }
+        offs[(size_t)i] = total;
+        total += (nbytes[i] + 15) / 16 * 16;
+    }
+    int rc = ensure_stage(e, total);
+    if (rc != ZLY_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream), ZLY_ERR_INFERENCE);        // pinned staging is reused call to call
+    for (int i = 0; i < n; ++i) memcpy(e->h_stage + offs[(size_t)i], bgr[i], nbytes[i]);
+    HIP_TRY(hipMemcpyAsync(e->d_stage, e->h_stage, total, hipMemcpyHostToDevice, e->stream), ZLY_ERR_INFERENCE);
+    rc = set_desc(e, n, w, h, offs.data(), e->stream);
+    if (rc != ZLY_OK) return rc;
+    rc = run_path(e, n, e->d_stage, nullptr, 0, e->stream, true);
+    if (rc != ZLY_OK) { e->stats.inference_errors++; return rc; }
+    const size_t sb = slab_bytes_of(e);
+    HIP_TRY(hipMemcpyAsync(e->h_slabs, e->d_slabs, sb * (size_t)n, hipMemcpyDeviceToHost, e->stream), ZLY_ERR_INFERENCE);
+    HIP_TRY(hipStreamSynchronize(e->stream), ZLY_ERR_INFERENCE);
+    const uint64_t ts = now_ms();                                        // onnx_engine.cpp:813-815
+    for (int i = 0; i < n; ++i) {
+        const zly_slab_header* hd = reinterpret_cast<const zly_slab_header*>(e->h_slabs + sb * (size_t)i);
+        const zly_det* d = reinterpret_cast<const zly_det*>(hd + 1);
+        int m = hd->n_kept;
+        if (m > e->cfg.max_dets) m = e->cfg.max_dets;
+        if (m > cap) m = cap;
+        for (int k = 0; k < m; ++k) { out[(size_t)i * cap + k] = d[k]; out[(size_t)i * cap + k].timestamp = ts; }
+        n_out[i] = hd->n_kept;
+    }
+    e->stats.inference_count += (uint64_t)n;
+    return ZLY_OK;
+}
+
+int32_t zly_detect(zly_engine* e, const uint8_t* bgr, size_t nbytes, int32_t w, int32_t h, zly_det* out, int32_t cap, int32_t* n_out)
+{
+    if (!e) return fail(ZLY_ERR_NOT_INITIALIZED, "Engine not running");
+    if (!out || !n_out || cap < 0) return fail(ZLY_ERR_INVALID_ARGUMENT, "null output");
+    std::lock_guard<std::mutex> lk(e->mu);
+    const auto t0 = std::chrono::steady_clock::now();
+    const uint8_t* ptrs[1] = {bgr};
+    int rc = detect_host_locked(e, 1, ptrs, &nbytes, &w, &h, out, cap, n_out);
+    e->stats.last_detect_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
+}
+
+int32_t zly_detect_batch(zly_engine* e, int32_t n, const uint8_t* const* bgr, const size_t* nbytes,
+                         const int32_t* w, const int32_t* h, zly_det* out, int32_t cap, int32_t* n_out)
+{
+    if (!e) return fail(ZLY_ERR_NOT_INITIALIZED, "Engine not running");
+    if (!bgr || !nbytes || !w || !h || !out || !n_out || cap < 0) return fail(ZLY_ERR_INVALID_ARGUMENT, "null argument");
+    if (n < 1 || n > e->cfg.max_batch) return fail(ZLY_ERR_INVALID_ARGUMENT, "batch size out of range");
+    std::lock_guard<std::mutex> lk(e->mu);
+    return detect_host_locked(e, n, bgr, nbytes, w, h, out, cap, n_out);
+}
+
+int32_t zly_detect_device(zly_engine* e, int32_t n, const void* d_frames, int32_t w, int32_t h, void* d_slabs, uint32_t frame_tag0, void* stream)
+{
+    if (!e) return fail(ZLY_ERR_NOT_INITIALIZED, "Engine not running");
+    if (!d_frames || w <= 0 || h <= 0) return fail(ZLY_ERR_INVALID_INPUT, "bad frame pointer or size");
+    if (n < 1 || n > e->cfg.max_batch) return fail(ZLY_ERR_INVALID_ARGUMENT, "batch size out of range");
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIP_TRY(hipSetDevice(e->dev), ZLY_ERR_SYSTEM);
+    hipStream_t s = stream ? (hipStream_t)stream : e->stream;
+    std::vector<int32_t> ws((size_t)n, w), hs((size_t)n, h);
+    std::vector<size_t> offs((size_t)n);
+    for (int i = 0; i < n; ++i) offs[(size_t)i] = (size_t)i * (size_t)w * (size_t)h * 3u;
+    int rc = set_desc(e, n, ws.data(), hs.data(), offs.data(), s);
+    if (rc != ZLY_OK) return rc;
+    rc = run_path(e, n, (const uint8_t*)d_frames, d_slabs, frame_tag0, s, true);
+    if (rc != ZLY_OK) { e->stats.inference_errors++; return rc; }
+    e->stats.inference_count += (uint64_t)n;
+    return ZLY_OK;
+}
+
+size_t zly_slab_bytes(const zly_engine* e) { return e ? slab_bytes_of(e) : 0; }
+
+int32_t zly_sync(zly_engine* e)
+{
+    if (!e) return fail(ZLY_ERR_NOT_INITIALIZED, "Engine not running");
+    HIP_TRY(hipSetDevice(e->dev), ZLY_ERR_SYSTEM);
+    HIP_TRY(hipStreamSynchronize(e->stream), ZLY_ERR_INFERENCE);
+    return ZLY_OK;
+}
+
+int32_t zly_read_slabs(zly_engine* e, int32_t n, void* host_slabs)
+{
+    if (!e) return fail(ZLY_ERR_NOT_INITIALIZED, "Engine not running");
+    if (!host_slabs || n < 1 || n > e->cfg.max_batch) return fail(ZLY_ERR_INVALID_ARGUMENT, "bad argument");
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIP_TRY(hipSetDevice(e->dev), ZLY_ERR_SYSTEM);
+    HIP_TRY(hipMemcpyAsync(host_slabs, e->d_slabs, slab_bytes_of(e) * (size_t)n, hipMemcpyDeviceToHost, e->stream), ZLY_ERR_INFERENCE);
+    HIP_TRY(hipStreamSynchronize(e->stream), ZLY_ERR_INFERENCE);
+    return ZLY_OK;
+}
+
+int32_t zly_preprocess(zly_engine* e, const uint8_t* bgr, size_t nbytes, int32_t w, int32_t h, float* out_nchw)
+{
+    if (!e) return fail(ZLY_ERR_NOT_INITIALIZED, "Engine not running");
+    if (!out_nchw) return fail(ZLY_ERR_INVALID_ARGUMENT, "null output");
+    if (!bgr || w <= 0 || h <= 0 || nbytes != (size_t)w * (size_t)h * 3u)
+        return fail(ZLY_ERR_INVALID_INPUT, "Invalid image data size: expected " + std::to_string((size_t)(w > 0 ? w : 0) * (size_t)(h > 0 ? h : 0) * 3u) + ", got " + std::to_string(nbytes));
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIP_TRY(hipSetDevice(e->dev), ZLY_ERR_SYSTEM);
+    int rc = ensure_stage(e, nbytes);
+    if (rc != ZLY_OK) return rc;
+    const size_t elems = (size_t)3 * e->cfg.model_w * e->cfg.model_h;
+    rc = ensure_scratch_f32(e, elems);
+    if (rc != ZLY_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream), ZLY_ERR_INFERENCE);
+    memcpy(e->h_stage, bgr, nbytes);
+    HIP_TRY(hipMemcpyAsync(e->d_stage, e->h_stage, nbytes, hipMemcpyHostToDevice, e->stream), ZLY_ERR_INFERENCE);
+    size_t off0 = 0;
+    rc = set_desc(e, 1, &w, &h, &off0, e->stream);
+    if (rc != ZLY_OK) return rc;
+    HIP_TRY(launch_preprocess(e->dtype, e->d_stage, e->d_desc, 1, nullptr, e->d_scratch_f32, e->cfg.model_w, e->cfg.model_h, e->stream), ZLY_ERR_INFERENCE);
+    HIP_TRY(hipMemcpyAsync(out_nchw, e->d_scratch_f32, elems * sizeof(float), hipMemcpyDeviceToHost, e->stream), ZLY_ERR_INFERENCE);
+    HIP_TRY(hipStreamSynchronize(e->stream), ZLY_ERR_INFERENCE);
+    return ZLY_OK;
+}
+
+int32_t zly_forward(zly_engine* e, int32_t n, const float* images_nchw, float* head_out)
+{
+    if (!e) return fail(ZLY_ERR_NOT_INITIALIZED, "Engine not running");
+    if (!images_nchw || !head_out) return fail(ZLY_ERR_INVALID_ARGUMENT, "null argument");
+    if (n < 1 || n > e->cfg.max_batch) return fail(ZLY_ERR_INVALID_ARGUMENT, "batch size out of range");
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIP_TRY(hipSetDevice(e->dev), ZLY_ERR_SYSTEM);
+    const size_t elems = (size_t)n * 3 * e->cfg.model_w * e->cfg.model_h;
+    int rc = ensure_scratch_f32(e, elems);
+    if (rc != ZLY_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(e->d_scratch_f32, images_nchw, elems * sizeof(float), hipMemcpyHostToDevice, e->stream), ZLY_ERR_INFERENCE);
+    HIP_TRY(launch_nchw_to_nhwc8(e->dtype, e->d_scratch_f32, e->bufs[(size_t)e->in_buf].ptr, n, e->cfg.model_w, e->cfg.model_h, e->stream), ZLY_ERR_INFERENCE);
+    // frames are model-sized for the purposes of the (unused) decode that follows
+    std::vector<int32_t> ws((size_t)n, e->cfg.model_w), hs((size_t)n, e->cfg.model_h);
+    std::vector<size_t> offs((size_t)n, 0);
+    rc = set_desc(e, n, ws.data(), hs.data(), offs.data(), e->stream);
+    if (rc != ZLY_OK) return rc;
+    rc = run_path(e, n, nullptr, nullptr, 0, e->stream, false);
+    if (rc != ZLY_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(head_out, e->d_head, (size_t)n * (4 + (size_t)e->nc) * e->N * sizeof(float), hipMemcpyDeviceToHost, e->stream), ZLY_ERR_INFERENCE);
+    HIP_TRY(hipStreamSynchronize(e->stream), ZLY_ERR_INFERENCE);
+    return ZLY_OK;
+}
+
+int32_t zly_head_tensor(zly_engine* e, int32_t idx, float* head_out)
+{
+    if (!e) return fail(ZLY_ERR_NOT_INITIALIZED, "Engine not running");
+    if (!head_out || idx < 0 || idx >= e->cfg.max_batch) return fail(ZLY_ERR_INVALID_ARGUMENT, "bad argument");
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIP_TRY(hipSetDevice(e->dev), ZLY_ERR_SYSTEM);
+    const size_t per = (4 + (size_t)e->nc) * e->N;
+    HIP_TRY(hipMemcpyAsync(head_out, e->d_head + per * (size_t)idx, per * sizeof(float), hipMemcpyDeviceToHost, e->stream), ZLY_ERR_INFERENCE);
+    HIP_TRY(hipStreamSynchronize(e->stream), ZLY_ERR_INFERENCE);
+    return ZLY_OK;
+}
+
+int32_t zly_postprocess(zly_engine* e, const float* head, int32_t num_classes, int32_t num_boxes, int32_t img_w, int32_t img_h,
+                        float conf_thr, float iou_thr, zly_det* out, int32_t cap, int32_t* n_out, int32_t* n_candidates)
+{
+    if (!e) return fail(ZLY_ERR_NOT_INITIALIZED, "Engine not running");
+    if (!head || !out || !n_out || num_classes < 1 || num_classes > 1024 || num_boxes < 0 || cap < 1 || img_w <= 0 || img_h <= 0)
+        return fail(ZLY_ERR_INVALID_ARGUMENT, "bad argument");
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIP_TRY(hipSetDevice(e->dev), ZLY_ERR_SYSTEM);
+    *n_out = 0;
+    if (n_candidates) *n_candidates = 0;
+    if (num_boxes == 0) return ZLY_OK;
+    const size_t N = (size_t)num_boxes;
+    const size_t head_bytes = (4 + (size_t)num_classes) * N * sizeof(float);
+    const size_t slab = sizeof(zly_slab_header) + (size_t)cap * sizeof(zly_det);
+    // one-off device scratch: [head | cand | scratch | count | desc | slab]
+    size_t off_cand = (head_bytes + 255) / 256 * 256;
+    size_t off_scr = off_cand + (N * sizeof(Cand) + 255) / 256 * 256;
+    size_t off_cnt = off_scr + (N * sizeof(Cand) + 255) / 256 * 256;
+    size_t off_desc = off_cnt + 256;
+    size_t off_slab = off_desc + 256;
+    size_t total = off_slab + slab;
+    char* d = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, total), ZLY_ERR_SYSTEM);
+    std::vector<unsigned char> hslab(slab);
+    FrameDesc fd; fd.src_off = 0; fd.w = img_w; fd.h = img_h;
+    hipError_t r = hipMemcpyAsync(d, head, head_bytes, hipMemcpyHostToDevice, e->stream);
+    if (r == hipSuccess) r = hipMemcpyAsync(d + off_desc, &fd, sizeof fd, hipMemcpyHostToDevice, e->stream);
+    if (r == hipSuccess) r = hipMemsetAsync(d + off_cnt, 0, sizeof(int), e->stream);
+    if (r == hipSuccess) r = launch_decode((const float*)d, num_classes, num_boxes, 1, (const FrameDesc*)(d + off_desc), conf_thr,
+                                           (Cand*)(d + off_cand), (int*)(d + off_cnt), e->stream);
+    if (r == hipSuccess) r = launch_nms((const Cand*)(d + off_cand), (const int*)(d + off_cnt), num_boxes, 1, iou_thr, num_classes,
+                                        (Cand*)(d + off_scr), d + off_slab, cap, 0, e->stream);
+    if (r == hipSuccess) r = hipMemcpyAsync(hslab.data(), d + off_slab, slab, hipMemcpyDeviceToHost, e->stream);
+    if (r == hipSuccess) r = hipStreamSynchronize(e->stream);
+    hipFree(d);
+    if (r != hipSuccess) return fail(ZLY_ERR_INFERENCE, std::string("postprocess: ") + hipGetErrorString(r));
+    const zly_slab_header* hd = reinterpret_cast<const zly_slab_header*>(hslab.data());
+    const zly_det* dd = reinterpret_cast<const zly_det*>(hd + 1);
+    const int m = hd->n_kept < cap ? hd->n_kept : cap;
+    for (int k = 0; k < m; ++k) out[k] = dd[k];
+    *n_out = hd->n_kept;
+    if (n_candidates) *n_candidates = hd->n_candidates;
+    return ZLY_OK;
+}
+
+int32_t zly_debug_tap(zly_engine* e, const char* name, int32_t idx, float* out, size_t cap_floats, int32_t* c, int32_t* h, int32_t* w)
+{
+    if (!e) return fail(ZLY_ERR_NOT_INITIALIZED, "Engine not running");
+    if (!name || !out || idx < 0 || idx >= e->cfg.max_batch) return fail(ZLY_ERR_INVALID_ARGUMENT, "bad argument");
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIP_TRY(hipSetDevice(e->dev), ZLY_ERR_SYSTEM);
+    int buf = -1, co = 0, C = 0;
+    bool f32 = false;
+    if (std::string(name) == "images") { buf = e->in_buf; co = 0; C = 3; }
+    else {
+        auto it = e->tap_index.find(name);
+        if (it == e->tap_index.end()) return fail(ZLY_ERR_INVALID_ARGUMENT, std::string("unknown tap: ") + name);
+        const Op& op = e->ops[(size_t)it->second.first];
+        buf = op.out.buf; co = op.out.co + op.tap_co[(size_t)it->second.second]; C = op.tap_c[(size_t)it->second.second];
+        f32 = op.out_f32 != 0;
+    }
+    const Buffer& b = e->bufs[(size_t)buf];
+    const size_t elems = (size_t)C * b.H * b.W;
+    if (elems > cap_floats) return fail(ZLY_ERR_INVALID_ARGUMENT, "tap output buffer too small");
+    int rc = ensure_scratch_f32(e, elems);
+    if (rc != ZLY_OK) return rc;
+    HIP_TRY(launch_tap_to_nchw(f32 ? ZLY_DTYPE_FP32 : e->dtype, b.ptr, b.C, co, C, b.H, b.W, idx, e->d_scratch_f32, e->stream), ZLY_ERR_INFERENCE);
+    HIP_TRY(hipMemcpyAsync(out, e->d_scratch_f32, elems * sizeof(float), hipMemcpyDeviceToHost, e->stream), ZLY_ERR_INFERENCE);
+    HIP_TRY(hipStreamSynchronize(e->stream), ZLY_ERR_INFERENCE);
+    if (c) *c = C;
+    if (h) *h = b.H;
+    if (w) *w = b.W;
+    return ZLY_OK;
+}
+
+int32_t zly_num_classes(const zly_engine* e) { return e ? e->nc : 0; }
+int32_t zly_num_anchors(const zly_engine* e) { return e ? e->N : 0; }
+int32_t zly_num_ops(const zly_engine* e) { return e ? (int32_t)e->ops.size() : 0; }
+
+int32_t zly_op_info_at(const zly_engine* e, int32_t i, zly_op_info* out)
+{
+    if (!e || !out || i < 0 || i >= (int32_t)e->ops.size()) return fail(ZLY_ERR_INVALID_ARGUMENT, "bad argument");
+    const Op& op = e->ops[(size_t)i];
+    memset(out, 0, sizeof *out);
+    snprintf(out->name, sizeof out->name, "%s", op.name.c_str());
+    out->kind = op.kind;
+    out->flops_per_frame = op.flops;
+    out->bytes_per_frame = op.bytes;
+    return ZLY_OK;
+}
+
+int32_t zly_profile_ops(zly_engine* e, int32_t n, const void* d_frames, int32_t w, int32_t h, int32_t reps, float* ms_out)
+{
+    if (!e) return fail(ZLY_ERR_NOT_INITIALIZED, "Engine not running");
+    if (!d_frames || !ms_out || reps < 1 || n < 1 || n > e->cfg.max_batch) return fail(ZLY_ERR_INVALID_ARGUMENT, "bad argument");
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIP_TRY(hipSetDevice(e->dev), ZLY_ERR_SYSTEM);
+    std::vector<int32_t> ws((size_t)n, w), hs((size_t)n, h);
+    std::vector<size_t> offs((size_t)n);
+    for (int i = 0; i < n; ++i) offs[(size_t)i] = (size_t)i * (size_t)w * (size_t)h * 3u;
+    int rc = set_desc(e, n, ws.data(), hs.data(), offs.data(), e->stream);
+    if (rc != ZLY_OK) return rc;
+    const size_t nops = e->ops.size();
+    std::vector<hipEvent_t> ev(nops + 1);
+    for (hipEvent_t& x : ev) HIP_TRY(hipEventCreate(&x), ZLY_ERR_SYSTEM);
+    std::vector<double> acc(nops, 0.0);
+    int rcode = ZLY_OK;
+    for (int r = 0; r < reps && rcode == ZLY_OK; ++r) {
+        hipEventRecord(ev[0], e->stream);
+        for (size_t i = 0; i < nops; ++i) {
+            hipError_t hr = run_op(e, e->ops[i], n, (const uint8_t*)d_frames, nullptr, 0, e->stream);
+            if (hr != hipSuccess) { rcode = fail(ZLY_ERR_INFERENCE, std::string("profile: ") + hipGetErrorString(hr)); break; }
+            hipEventRecord(ev[i + 1], e->stream);
+        }
+        if (rcode != ZLY_OK) break;
+        if (hipStreamSynchronize(e->stream) != hipSuccess) { rcode = fail(ZLY_ERR_INFERENCE, "profile: sync failed"); break; }
+        for (size_t i = 0; i < nops; ++i) {
+            float ms = 0.f;
+            hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
+            acc[i] += ms;
+        }
+    }
+    for (hipEvent_t& x : ev) hipEventDestroy(x);
+    if (rcode != ZLY_OK) return rcode;
+    for (size_t i = 0; i < nops; ++i) {
+        ms_out[i] = (float)(acc[i] / reps);
+        const int k = e->ops[i].kind;
+        if (k == OP_PREPROCESS) e->stats.total_preprocess_ms += acc[i];
+        else if (k == OP_DECODE || k == OP_NMS) e->stats.total_postprocess_ms += acc[i];
+        else e->stats.total_forward_ms += acc[i];
+    }
+    e->last_n = n;
+    return ZLY_OK;
+}
+
+int32_t zly_get_stats(const zly_engine* e, zly_stats* out)
+{
+    if (!e || !out) return fail(ZLY_ERR_INVALID_ARGUMENT, "bad argument");
+    *out = e->stats;
+    return ZLY_OK;
+}
+
+}  // extern "C"

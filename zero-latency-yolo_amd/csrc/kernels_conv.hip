@@ -1,0 +1,229 @@
+// kernels_conv.hip -- implicit-GEMM convolution on gfx950 matrix cores (MFMA), NHWC.
+//
+// Replaces the conv/Gemm nodes that the reference executes inside Ort::Session::Run
+// (reference src/inference/onnx_engine.cpp:578-585; ORT 1.8.1 CPU EP, not in the reference tree).
+//
+// GEMM view:  D[cout][pixel] = sum_k  Wt[cout][k] * X[k][pixel],   k = (ky, kx, ci)
+//   * the WEIGHTS are the MFMA "A" operand (rows = output channels), the ACTIVATIONS the "B" operand
+//     (columns = output pixels).  With v_mfma_f32_16x16x32_bf16 a lane then ends up holding 4
+//     CONSECUTIVE output channels of one pixel, which is exactly one 8-byte (bf16) / 16-byte (fp32)
+//     NHWC store -- the transposed assignment would scatter 2-byte stores.
+//   * NHWC makes the 8 k-values a lane needs (8 consecutive input channels of one tap) one 16-byte
+//     load, so fragments come straight from global memory: no im2col buffer, no LDS round trip.
+//   * weights are pre-tiled on the host as [cout/16][k/KSTEP][16][KSTEP], so one weight fragment for
+//     the whole wave is one contiguous 1 KiB read (weights.cpp: repack_conv).
+//   * bias + SiLU + optional residual add + write-at-channel-offset (free Concat / split) are fused
+//     into the epilogue.
+// fp32 mode uses v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain) with a permuted k order inside each
+// 16-wide k-step so that both operands still arrive as 16-byte loads.
+#include "zly_internal.h"
+
+namespace zly {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+template <typename T> struct Frag;
+template <> struct Frag<bf16_t> { typedef bf16x8 type; static constexpr int EPL = 8; static constexpr int KSTEP = 32; };
+template <> struct Frag<float>  { typedef f32x4  type; static constexpr int EPL = 4; static constexpr int KSTEP = 16; };
+
+__device__ __forceinline__ f32x4 mma_step(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+// 16x16x4 f32: lane l supplies A[l&15][l>>4] and B[l>>4][l&15].  Element j of the 4 floats each lane
+// loaded is used by MFMA j, i.e. MFMA j sums k = {4q + j : q = 0..3}; both operands use the same
+// permutation, and over j = 0..3 every k of the 16-wide step is covered exactly once.
+__device__ __forceinline__ f32x4 mma_step(f32x4 a, f32x4 b, f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], c, 0, 0, 0);
+    return c;
+}
+
+template <typename T> __device__ __forceinline__ float silu(float v);
+template <> __device__ __forceinline__ float silu<float>(float v) { return v / (1.0f + expf(-v)); }
+template <> __device__ __forceinline__ float silu<bf16_t>(float v) { return v * __frcp_rn(1.0f + __expf(-v)); }
+
+__device__ __forceinline__ void store4(bf16_t* p, f32x4 v) {
+    bf16x4 o;
+    o[0] = (bf16_t)v[0]; o[1] = (bf16_t)v[1]; o[2] = (bf16_t)v[2]; o[3] = (bf16_t)v[3];
+    *reinterpret_cast<bf16x4*>(p) = o;
+}
+__device__ __forceinline__ void store4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ f32x4 load4(const bf16_t* p) {
+    bf16x4 i = *reinterpret_cast<const bf16x4*>(p);
+    f32x4 o = {(float)i[0], (float)i[1], (float)i[2], (float)i[3]};
+    return o;
+}
+__device__ __forceinline__ f32x4 load4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+// MODE 0: 1x1 conv.  MODE 1: 3x3, Cin % KSTEP == 0 (a k-step never straddles a tap; tap/ci advance
+// incrementally).  MODE 2: 3x3, any Cin % EPL == 0 (per-step division).
+// One wave owns PT 16-pixel tiles x CT 16-channel tiles; a 256-thread workgroup is 4 waves on
+// consecutive pixel tiles of the same channel block (they share the weight fragments through L1).
+template <typename T, int MODE, int CT, int PT>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
+{
+    typedef typename Frag<T>::type F;
+    constexpr int EPL = Frag<T>::EPL;
+    constexpr int KSTEP = Frag<T>::KSTEP;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int p = lane & 15;       // pixel within a 16-pixel tile (MFMA B column / D column)
+    const int kq = lane >> 4;      // which 8-wide (4-wide for fp32) k group this lane feeds
+    const int m_base = (blockIdx.x * 4 + wave) * (PT * 16);
+    if (m_base >= a.M) return;     // wave-uniform; the kernel has no barriers
+
+    const T* __restrict__ in = static_cast<const T*>(a.in);
+
+    int boff[PT], iy0[PT], ix0[PT];
+    bool mval[PT];
+#pragma unroll
+    for (int t = 0; t < PT; ++t) {
+        const int m = m_base + t * 16 + p;
+        mval[t] = m < a.M;
+        const int mm = mval[t] ? m : 0;
+        const int ox = mm % a.Wo;
+        const int r = mm / a.Wo;
+        const int oy = r % a.Ho;
+        const int b = r / a.Ho;
+        iy0[t] = oy * a.stride - a.pad;
+        ix0[t] = ox * a.stride - a.pad;
+        boff[t] = ((b * a.H + iy0[t]) * a.W + ix0[t]) * a.in_cs + a.in_co;
+    }
+
+    f32x4 acc[CT][PT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int t = 0; t < PT; ++t) acc[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    constexpr int WTILE = 16 * KSTEP;
+    const T* __restrict__ wp = static_cast<const T*>(a.wgt) +
+                               (size_t)(blockIdx.y * CT) * a.nk * WTILE + p * KSTEP + kq * EPL;
+
+    int tap = 0, cbase = 0;        // MODE 1 running position
+    for (int s = 0; s < a.nk; ++s) {
+        F wf[CT];
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+            wf[c] = *reinterpret_cast<const F*>(wp + ((size_t)c * a.nk + s) * WTILE);
+
+        int ci, ky, kx;
+        bool kval;
+        if (MODE == 0) {
+            ci = s * KSTEP + kq * EPL; ky = 0; kx = 0; kval = ci < a.Cin;
+        } else if (MODE == 1) {
+            ci = cbase + kq * EPL; ky = tap / 3; kx = tap - ky * 3; kval = true;
+        } else {
+            const int k = s * KSTEP + kq * EPL;
+            const int tp = k / a.Cin;
+            ci = k - tp * a.Cin; ky = tp / 3; kx = tp - ky * 3; kval = tp < 9;
+        }
+        const int koff = (ky * a.W + kx) * a.in_cs + ci;
+
+        F af[PT];
+#pragma unroll
+        for (int t = 0; t < PT; ++t) {
+            const int iy = iy0[t] + ky, ix = ix0[t] + kx;
+            const bool ok = mval[t] && kval && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            F z;
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) z[j] = (T)0.0f;
+            af[t] = ok ? *reinterpret_cast<const F*>(in + (long)(boff[t] + koff)) : z;
+        }
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int t = 0; t < PT; ++t) acc[c][t] = mma_step(wf[c], af[t], acc[c][t]);
+
+        if (MODE == 1) {
+            cbase += KSTEP;
+            if (cbase == a.Cin) { cbase = 0; ++tap; }
+        }
+    }
+
+    // epilogue: lane holds channels ch..ch+3 of pixel m for every (c, t)
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        const int ch = (blockIdx.y * CT + c) * 16 + kq * 4;
+        if (ch >= a.Cout) continue;
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(a.bias + ch);
+#pragma unroll
+        for (int t = 0; t < PT; ++t) {
+            const int m = m_base + t * 16 + p;
+            if (m >= a.M) continue;
+            f32x4 v = acc[c][t] + bias;
+            if (a.act) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = silu<T>(v[r]);
+            }
+            if (a.res) {
+                const T* rp = static_cast<const T*>(a.res) + (size_t)m * a.res_cs + a.res_co + ch;
+                v += load4(rp);
+            }
+            if (a.out_f32) store4(static_cast<float*>(a.out) + (size_t)m * a.out_cs + a.out_co + ch, v);
+            else           store4(static_cast<T*>(a.out) + (size_t)m * a.out_cs + a.out_co + ch, v);
+        }
+    }
+}
+
+typedef void (*conv_fn)(const ConvArgs);
+
+template <typename T, int MODE, int PT>
+static conv_fn pick_ct(int ct) {
+    switch (ct) {
+        case 1: return conv_igemm_kernel<T, MODE, 1, PT>;
+        case 2: return conv_igemm_kernel<T, MODE, 2, PT>;
+        case 3: return conv_igemm_kernel<T, MODE, 3, PT>;
+        case 4: return conv_igemm_kernel<T, MODE, 4, PT>;
+        case 5: return conv_igemm_kernel<T, MODE, 5, PT>;
+    }
+    return nullptr;
+}
+template <typename T, int PT>
+static conv_fn pick_mode(int mode, int ct) {
+    switch (mode) {
+        case 0: return pick_ct<T, 0, PT>(ct);
+        case 1: return pick_ct<T, 1, PT>(ct);
+        case 2: return pick_ct<T, 2, PT>(ct);
+    }
+    return nullptr;
+}
+
+int conv_kstep(int dtype) { return dtype == ZLY_DTYPE_BF16 ? Frag<bf16_t>::KSTEP : Frag<float>::KSTEP; }
+
+void conv_pick_config(int dtype, int ks, int cin, int cout_pad, int M, ConvLaunch* cfg)
+{
+    const int kstep = conv_kstep(dtype);
+    cfg->ks = ks;
+    cfg->fastk = (ks == 3 && cin % kstep == 0) ? 1 : 0;
+    const int ntiles = cout_pad / 16;
+    static const int pref[5] = {4, 5, 3, 2, 1};
+    cfg->ct = 1;
+    for (int i = 0; i < 5; ++i)
+        if (ntiles % pref[i] == 0) { cfg->ct = pref[i]; break; }
+    // two pixel tiles per wave only once the grid would still hold >= 4 workgroups per CU
+    const long wgs_pt2 = ((long)(M + 127) / 128) * (ntiles / cfg->ct);
+    cfg->pt = (dtype == ZLY_DTYPE_BF16 && wgs_pt2 < 1024) ? 1 : 2;
+}
+
+hipError_t launch_conv(int dtype, const ConvArgs& a, const ConvLaunch& cfg, hipStream_t s)
+{
+    const int mode = cfg.ks == 1 ? 0 : (cfg.fastk ? 1 : 2);
+    conv_fn fn = nullptr;
+    if (dtype == ZLY_DTYPE_BF16) fn = cfg.pt == 1 ? pick_mode<bf16_t, 1>(mode, cfg.ct) : pick_mode<bf16_t, 2>(mode, cfg.ct);
+    else                         fn = pick_mode<float, 2>(mode, cfg.ct);
+    if (!fn) return hipErrorInvalidValue;
+    const int cout_pad = (a.Cout + 15) / 16 * 16;
+    const int ytiles = cout_pad / (16 * cfg.ct);
+    const int px_per_wg = 64 * cfg.pt;
+    dim3 grid((a.M + px_per_wg - 1) / px_per_wg, ytiles, 1);
+    hipLaunchKernelGGL(fn, grid, dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace zly

@@ -1,0 +1,278 @@
+// kernels_misc.hip -- the non-GEMM stages of the detect path on gfx950: preprocess, SPPF max-pools,
+// nearest-2x upsample, Detect-head decode (DFL + dist2bbox + sigmoid).  All HBM/LDS-bound byte and
+// element work: coalesced 16-byte accesses, no MFMA.
+#include "zly_internal.h"
+
+namespace zly {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// ------------------------------------------------------------------------------------------------
+// preprocess: stretch nearest-neighbour resize + BGR->RGB + /255
+// reference OnnxInferenceEngine::preProcess, src/inference/onnx_engine.cpp:649-700:
+//   scale_w = float(w)/tw, scale_h = float(h)/th                       (:673-674)
+//   src_y = min(int(y*scale_h), h-1); src_x = min(int(x*scale_w), w-1)  (:681-682)
+//   out[c][y][x] = src[(src_y*w + src_x)*3 + (2-c)] / 255.0f            (:685,:693)
+// Every operation is a single IEEE fp32 op, so the result is bit-identical to the CPU oracle.
+// Two outputs: the engine's NHWC tensor padded to 8 channels (one 16-byte store per pixel in bf16),
+// and optionally the reference's planar fp32 [3][th][tw] layout for the parity entry point.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t* __restrict__ src, const FrameDesc* __restrict__ desc,
+                                                         T* __restrict__ out8, float* __restrict__ out_nchw, int tw, int th)
+{
+    const int f = blockIdx.y;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= tw * th) return;
+    const int y = idx / tw, x = idx - y * tw;
+    const FrameDesc d = desc[f];
+    const float scale_w = (float)d.w / (float)tw;
+    const float scale_h = (float)d.h / (float)th;
+    int sy = (int)((float)y * scale_h); if (sy > d.h - 1) sy = d.h - 1;
+    int sx = (int)((float)x * scale_w); if (sx > d.w - 1) sx = d.w - 1;
+    const uint8_t* px = src + d.src_off + ((size_t)sy * d.w + sx) * 3;
+    const float b = (float)px[0] / 255.0f, g = (float)px[1] / 255.0f, r = (float)px[2] / 255.0f;
+    if (out8) {
+        T* o = out8 + ((size_t)f * th * tw + idx) * 8;
+        o[0] = (T)r; o[1] = (T)g; o[2] = (T)b; o[3] = (T)0.f;
+        o[4] = (T)0.f; o[5] = (T)0.f; o[6] = (T)0.f; o[7] = (T)0.f;
+    }
+    if (out_nchw) {
+        float* o = out_nchw + (size_t)f * 3 * th * tw;
+        o[idx] = r; o[(size_t)th * tw + idx] = g; o[(size_t)2 * th * tw + idx] = b;
+    }
+}
+
+hipError_t launch_preprocess(int dtype, const uint8_t* src, const FrameDesc* desc, int n,
+                             void* out_nhwc8, float* out_nchw_f32, int tw, int th, hipStream_t s)
+{
+    dim3 grid((tw * th + 255) / 256, n);
+    if (dtype == ZLY_DTYPE_BF16)
+        hipLaunchKernelGGL(preprocess_kernel<bf16_t>, grid, dim3(256), 0, s, src, desc, (bf16_t*)out_nhwc8, out_nchw_f32, tw, th);
+    else
+        hipLaunchKernelGGL(preprocess_kernel<float>, grid, dim3(256), 0, s, src, desc, (float*)out_nhwc8, out_nchw_f32, tw, th);
+    return hipGetLastError();
+}
+
+// fp32 planar [n][3][th][tw] (the "images" tensor of onnx_engine.cpp:560-569) -> engine NHWC8
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc8_kernel(const float* __restrict__ in, T* __restrict__ out8, int hw)
+{
+    const int f = blockIdx.y;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= hw) return;
+    const float* i = in + (size_t)f * 3 * hw;
+    T* o = out8 + ((size_t)f * hw + idx) * 8;
+    o[0] = (T)i[idx]; o[1] = (T)i[(size_t)hw + idx]; o[2] = (T)i[(size_t)2 * hw + idx]; o[3] = (T)0.f;
+    o[4] = (T)0.f; o[5] = (T)0.f; o[6] = (T)0.f; o[7] = (T)0.f;
+}
+
+hipError_t launch_nchw_to_nhwc8(int dtype, const float* in_nchw, void* out_nhwc8, int n, int tw, int th, hipStream_t s)
+{
+    dim3 grid((tw * th + 255) / 256, n);
+    if (dtype == ZLY_DTYPE_BF16)
+        hipLaunchKernelGGL(nchw_to_nhwc8_kernel<bf16_t>, grid, dim3(256), 0, s, in_nchw, (bf16_t*)out_nhwc8, tw * th);
+    else
+        hipLaunchKernelGGL(nchw_to_nhwc8_kernel<float>, grid, dim3(256), 0, s, in_nchw, (float*)out_nhwc8, tw * th);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// SPPF: three chained 5x5 stride-1 max-pools (pad 2, -inf outside).  The source is channel block 0
+// ([0,c)) of the SPPF concat buffer; pools 1..3 are written to channel blocks 1..3 of the same buffer,
+// so the following 1x1 conv reads the 4c-channel concat without a Concat op.
+// One workgroup = one frame x 8 channels: the HxWx8 tile lives in LDS as fp32 (max is exact on
+// bf16 values), each pool is a separable row pass + column pass between two LDS images.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void sppf_pool_kernel(T* __restrict__ buf, int cs, int c, int H, int W)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* A = lds;
+    float* B = lds + (size_t)H * W * 8;
+    const int f = blockIdx.y, c0 = blockIdx.x * 8;
+    const int hw = H * W, total = hw * 8;
+    T* base = buf + (size_t)f * hw * cs;
+    for (int e = threadIdx.x; e < total; e += 256) {
+        const int px = e >> 3, ch = e & 7;
+        A[e] = (float)base[(size_t)px * cs + c0 + ch];
+    }
+    __syncthreads();
+    for (int pool = 1; pool <= 3; ++pool) {
+        for (int e = threadIdx.x; e < total; e += 256) {          // row pass A -> B
+            const int px = e >> 3, ch = e & 7;
+            const int y = px / W, x = px - y * W;
+            float m = -INFINITY;
+            for (int dx = -2; dx <= 2; ++dx) {
+                const int xx = x + dx;
+                if (xx >= 0 && xx < W) m = fmaxf(m, A[((y * W + xx) << 3) + ch]);
+            }
+            B[e] = m;
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < total; e += 256) {          // column pass B -> A, and store
+            const int px = e >> 3, ch = e & 7;
+            const int y = px / W, x = px - y * W;
+            float m = -INFINITY;
+            for (int dy = -2; dy <= 2; ++dy) {
+                const int yy = y + dy;
+                if (yy >= 0 && yy < H) m = fmaxf(m, B[((yy * W + x) << 3) + ch]);
+            }
+            A[e] = m;
+            base[(size_t)px * cs + pool * c + c0 + ch] = (T)m;
+        }
+        __syncthreads();
+    }
+}
+
+hipError_t launch_sppf_pool(int dtype, void* buf, int cs, int c, int n, int H, int W, hipStream_t s)
+{
+    const size_t lds = (size_t)H * W * 8 * sizeof(float) * 2;
+    if (lds > 160 * 1024 || (c % 8) != 0) return hipErrorInvalidValue;
+    dim3 grid(c / 8, n);
+    if (dtype == ZLY_DTYPE_BF16) {
+        if (lds > 64 * 1024) hipFuncSetAttribute((const void*)sppf_pool_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(sppf_pool_kernel<bf16_t>, grid, dim3(256), lds, s, (bf16_t*)buf, cs, c, H, W);
+    } else {
+        if (lds > 64 * 1024) hipFuncSetAttribute((const void*)sppf_pool_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(sppf_pool_kernel<float>, grid, dim3(256), lds, s, (float*)buf, cs, c, H, W);
+    }
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// nearest 2x upsample of a channel slice into a channel slice of the consumer's concat buffer
+// (nn.Upsample(scale_factor=2, mode="nearest") + Concat of yolov8.yaml layers 10-11, 13-14).
+// One thread moves 16 bytes (8 bf16 / 4 fp32 channels).
+// ------------------------------------------------------------------------------------------------
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void upsample2x_kernel(const T* __restrict__ in, int in_cs, int in_co,
+                                                         T* __restrict__ out, int out_cs, int out_co,
+                                                         int C, int H, int W, long total)
+{
+    typedef __attribute__((ext_vector_type(VEC))) T V;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int cv = C / VEC;
+    const int chunk = (int)(i % cv);
+    long px = i / cv;                       // output pixel index over [n][2H][2W]
+    const int W2 = 2 * W, H2 = 2 * H;
+    const int x = (int)(px % W2); px /= W2;
+    const int y = (int)(px % H2);
+    const int f = (int)(px / H2);
+    const T* src = in + ((size_t)(f * H + (y >> 1)) * W + (x >> 1)) * in_cs + in_co + chunk * VEC;
+    T* dst = out + ((size_t)(f * H2 + y) * W2 + x) * out_cs + out_co + chunk * VEC;
+    *reinterpret_cast<V*>(dst) = *reinterpret_cast<const V*>(src);
+}
+
+hipError_t launch_upsample2x(int dtype, const void* in, int in_cs, int in_co, void* out, int out_cs, int out_co,
+                             int C, int n, int H, int W, hipStream_t s)
+{
+    if (dtype == ZLY_DTYPE_BF16) {
+        const long total = (long)n * 4 * H * W * (C / 8);
+        hipLaunchKernelGGL((upsample2x_kernel<bf16_t, 8>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                           (const bf16_t*)in, in_cs, in_co, (bf16_t*)out, out_cs, out_co, C, H, W, total);
+    } else {
+        const long total = (long)n * 4 * H * W * (C / 4);
+        hipLaunchKernelGGL((upsample2x_kernel<float, 4>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                           (const float*)in, in_cs, in_co, (float*)out, out_cs, out_co, C, H, W, total);
+    }
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Detect head decode for one pyramid level: DFL softmax-expectation over 16 bins per box side,
+// dist2bbox (xywh, anchor offset 0.5) * stride, class sigmoid -> rows of the [4+nc][N] fp32 head
+// tensor, i.e. the "output0" tensor the reference's postProcess indexes (onnx_engine.cpp:767-796).
+// logits: fp32 [n][H*W][64+nc] (box-branch logits then class logits, written by the two final 1x1
+// convs).  One workgroup = 64 anchors: logits staged through LDS so that both the global reads
+// (anchor-major) and the global writes (row-major over anchors) are coalesced.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ logits, int cs, int nc, int H, int W,
+                                                   float stride_px, float* __restrict__ head, int N_total, int anchor_off)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int ldw = cs + 1;                          // odd row pitch: conflict-free column reads
+    float* L = lds;                                  // [64][ldw]
+    float* dist = lds + 64 * ldw;                    // [4][64]
+    const int f = blockIdx.y;
+    const int hw = H * W;
+    const int a0 = blockIdx.x * 64;
+    const int na = min(64, hw - a0);
+    const float* src = logits + ((size_t)f * hw + a0) * cs;
+    for (int i = threadIdx.x; i < na * cs; i += 256) {
+        const int a = i / cs, c = i - a * cs;
+        L[a * ldw + c] = src[i];
+    }
+    __syncthreads();
+    const int a = threadIdx.x & 63, q = threadIdx.x >> 6;
+    if (a < na) {                                    // DFL for side q (0=l, 1=t, 2=r, 3=b)
+        const float* x = L + a * ldw + q * 16;
+        float mx = x[0];
+#pragma unroll
+        for (int j = 1; j < 16; ++j) mx = fmaxf(mx, x[j]);
+        float se = 0.f, sw = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float e = expf(x[j] - mx);
+            se += e;
+            sw += e * (float)j;
+        }
+        dist[q * 64 + a] = sw / se;
+    }
+    __syncthreads();
+    float* out = head + (size_t)f * (4 + nc) * N_total + anchor_off + a0;
+    if (a < na) {
+        const int ai = a0 + a;
+        const float ax = (float)(ai % W) + 0.5f, ay = (float)(ai / W) + 0.5f;
+        const float l = dist[a], t = dist[64 + a], r = dist[128 + a], b = dist[192 + a];
+        const float x1 = ax - l, y1 = ay - t, x2 = ax + r, y2 = ay + b;
+        float v;
+        if (q == 0) v = (x1 + x2) / 2.0f;
+        else if (q == 1) v = (y1 + y2) / 2.0f;
+        else if (q == 2) v = x2 - x1;
+        else v = y2 - y1;
+        out[(size_t)q * N_total + a] = v * stride_px;
+        for (int c = q; c < nc; c += 4) {
+            const float z = L[a * ldw + 64 + c];
+            out[(size_t)(4 + c) * N_total + a] = 1.0f / (1.0f + expf(-z));
+        }
+    }
+}
+
+hipError_t launch_head(const float* logits, int cs, int nc, int n, int H, int W, int stride_px,
+                       float* head, int N_total, int anchor_off, hipStream_t s)
+{
+    const size_t lds = ((size_t)64 * (cs + 1) + 256) * sizeof(float);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    if (lds > 64 * 1024) hipFuncSetAttribute((const void*)head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    dim3 grid((H * W + 63) / 64, n);
+    hipLaunchKernelGGL(head_kernel, grid, dim3(256), lds, s, logits, cs, nc, H, W, (float)stride_px, head, N_total, anchor_off);
+    return hipGetLastError();
+}
+
+// debug/parity: channel slice of frame idx -> fp32 planar [C][H][W]
+template <typename T>
+__global__ __launch_bounds__(256) void tap_kernel(const T* __restrict__ in, int cs, int co, int C, int hw, float* __restrict__ out)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)C * hw) return;
+    const int c = (int)(i / hw), px = (int)(i - (long)c * hw);
+    out[i] = (float)in[(size_t)px * cs + co + c];
+}
+
+hipError_t launch_tap_to_nchw(int dtype, const void* in, int cs, int co, int C, int H, int W, int idx, float* out, hipStream_t s)
+{
+    const int hw = H * W;
+    const long total = (long)C * hw;
+    dim3 grid((unsigned)((total + 255) / 256));
+    if (dtype == ZLY_DTYPE_BF16)
+        hipLaunchKernelGGL(tap_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)in + (size_t)idx * hw * cs, cs, co, C, hw, out);
+    else if (dtype == ZLY_DTYPE_FP32)
+        hipLaunchKernelGGL(tap_kernel<float>, grid, dim3(256), 0, s, (const float*)in + (size_t)idx * hw * cs, cs, co, C, hw, out);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+}  // namespace zly

@@ -1,0 +1,133 @@
+// weights.cpp -- ZLYW reader + repacker (pure host code).  The file format is documented in
+// tools/zly_model.py; it stands in for the .onnx file the reference loads in loadModel
+// (reference src/inference/onnx_engine.cpp:957-1062).
+#include "weights.h"
+#include "zly.h"
+
+#include <stdio.h>
+#include <string.h>
+
+namespace zly {
+
+namespace {
+#pragma pack(push, 1)
+struct FileHeader {
+    char magic[4];
+    uint32_t version, nc, reg_max;
+    uint32_t ch[5];
+    uint32_t n_c2f[8];
+    uint32_t num_convs;
+};
+struct FileRec {
+    char name[48];
+    uint32_t cin, cout, k, stride, act, pad;
+    uint64_t w_off, b_off;
+};
+#pragma pack(pop)
+static_assert(sizeof(FileHeader) == 4 + 4 * 17, "header layout");
+static_assert(sizeof(FileRec) == 48 + 24 + 16, "record layout");
+}  // namespace
+
+const ConvRec* ModelFile::find(const std::string& name) const
+{
+    for (const ConvRec& c : convs)
+        if (c.name == name) return &c;
+    return nullptr;
+}
+
+int load_zlyw(const char* path, ModelFile* out, std::string* err)
+{
+    FILE* f = path ? fopen(path, "rb") : nullptr;
+    if (!f) { *err = std::string("model file not found: ") + (path ? path : "(null)"); return ZLY_ERR_MODEL_NOT_FOUND; }
+    fseek(f, 0, SEEK_END);
+    const long size = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    std::vector<uint8_t> data((size_t)(size > 0 ? size : 0));
+    const size_t got = data.empty() ? 0 : fread(data.data(), 1, data.size(), f);
+    fclose(f);
+    if (got != data.size() || data.size() < sizeof(FileHeader)) { *err = "short read / not a ZLYW file"; return ZLY_ERR_MODEL_LOAD; }
+    FileHeader h;
+    memcpy(&h, data.data(), sizeof h);
+    if (memcmp(h.magic, "ZLYW", 4) != 0 || h.version != 1) { *err = "bad magic/version (expected ZLYW v1)"; return ZLY_ERR_MODEL_LOAD; }
+    if (h.num_convs == 0 || h.num_convs > 4096 ||
+        sizeof(FileHeader) + (size_t)h.num_convs * sizeof(FileRec) > data.size()) { *err = "corrupt conv table"; return ZLY_ERR_MODEL_LOAD; }
+    out->nc = (int)h.nc;
+    out->reg_max = (int)h.reg_max;
+    for (int i = 0; i < 5; ++i) out->ch[i] = (int)h.ch[i];
+    for (int i = 0; i < 8; ++i) out->n_c2f[i] = (int)h.n_c2f[i];
+    out->convs.clear();
+    out->convs.reserve(h.num_convs);
+    for (uint32_t i = 0; i < h.num_convs; ++i) {
+        FileRec r;
+        memcpy(&r, data.data() + sizeof(FileHeader) + (size_t)i * sizeof(FileRec), sizeof r);
+        ConvRec c;
+        char nm[49];
+        memcpy(nm, r.name, 48);
+        nm[48] = 0;
+        c.name = nm;
+        c.cin = (int)r.cin; c.cout = (int)r.cout; c.k = (int)r.k; c.stride = (int)r.stride; c.act = (int)r.act;
+        const size_t nw = (size_t)c.cout * c.cin * c.k * c.k;
+        if (c.cin <= 0 || c.cout <= 0 || (c.k != 1 && c.k != 3) || (c.stride != 1 && c.stride != 2) ||
+            r.w_off + nw * 4 > data.size() || r.b_off + (size_t)c.cout * 4 > data.size()) {
+            *err = "corrupt conv record: " + c.name;
+            return ZLY_ERR_MODEL_LOAD;
+        }
+        c.w.resize(nw);
+        c.b.resize((size_t)c.cout);
+        memcpy(c.w.data(), data.data() + r.w_off, nw * 4);
+        memcpy(c.b.data(), data.data() + r.b_off, (size_t)c.cout * 4);
+        out->convs.push_back(std::move(c));
+    }
+    return ZLY_OK;
+}
+
+uint16_t f32_to_bf16_rne(float f)
+{
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+void repack_conv(const std::vector<const ConvRec*>& srcs, int cin_store, int kstep, bool bf16,
+                 std::vector<uint8_t>* w_out, std::vector<float>* bias_out, int* cout_total, int* cout_pad, int* nk)
+{
+    const int ks = srcs[0]->k, cin = srcs[0]->cin;
+    int ctot = 0;
+    for (const ConvRec* s : srcs) ctot += s->cout;
+    const int cpad = (ctot + 15) / 16 * 16;
+    const int K = ks * ks * cin_store;
+    const int nkk = (K + kstep - 1) / kstep;
+    const size_t esz = bf16 ? 2 : 4;
+    w_out->assign((size_t)cpad * nkk * kstep * esz, 0);
+    bias_out->assign((size_t)cpad, 0.0f);
+    int co_base = 0;
+    for (const ConvRec* s : srcs) {
+        for (int co = 0; co < s->cout; ++co) {
+            const int row = co_base + co;
+            (*bias_out)[(size_t)row] = s->b[(size_t)co];
+            const int ct = row / 16, r = row % 16;
+            for (int ky = 0; ky < ks; ++ky)
+                for (int kx = 0; kx < ks; ++kx)
+                    for (int ci = 0; ci < cin; ++ci) {
+                        const int k = (ky * ks + kx) * cin_store + ci;
+                        const int st = k / kstep, kk = k % kstep;
+                        const size_t dst = (((size_t)ct * nkk + st) * 16 + r) * kstep + kk;
+                        const float v = s->w[(((size_t)co * cin + ci) * ks + ky) * ks + kx];
+                        if (bf16) {
+                            const uint16_t h = f32_to_bf16_rne(v);
+                            memcpy(w_out->data() + dst * 2, &h, 2);
+                        } else {
+                            memcpy(w_out->data() + dst * 4, &v, 4);
+                        }
+                    }
+        }
+        co_base += s->cout;
+    }
+    *cout_total = ctot;
+    *cout_pad = cpad;
+    *nk = nkk;
+}
+
+}  // namespace zly

@@ -1,0 +1,36 @@
+// weights.h -- ZLYW model file reader and the host-side weight repacker for the MFMA conv kernel.
+#pragma once
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+namespace zly {
+
+struct ConvRec {
+    std::string name;
+    int cin = 0, cout = 0, k = 0, stride = 0, act = 0;
+    std::vector<float> w;     // [cout][cin][k][k]
+    std::vector<float> b;     // [cout]
+};
+
+struct ModelFile {
+    int nc = 0, reg_max = 0;
+    int ch[5] = {0, 0, 0, 0, 0};
+    int n_c2f[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    std::vector<ConvRec> convs;
+    const ConvRec* find(const std::string& name) const;
+};
+
+// returns 0 or a ZLY_ERR_* code; *err receives a message
+int load_zlyw(const char* path, ModelFile* out, std::string* err);
+
+uint16_t f32_to_bf16_rne(float f);
+
+// Concatenates `srcs` along cout and lays the result out as the conv kernel reads it:
+//   [cout_pad/16][nk][16][kstep] with k = (ky*ks + kx)*cin_store + ci, zero padded.
+// cin_store is the channel count of the activation tensor the conv reads (>= cin; the stem reads an
+// 8-channel tensor for its 3 input channels).  bf16 -> 2-byte elements, else fp32.
+void repack_conv(const std::vector<const ConvRec*>& srcs, int cin_store, int kstep, bool bf16,
+                 std::vector<uint8_t>* w_out, std::vector<float>* bias_out, int* cout_total, int* cout_pad, int* nk);
+
+}  // namespace zly

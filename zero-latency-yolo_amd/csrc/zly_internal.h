@@ -1,0 +1,63 @@
+// zly_internal.h -- shared declarations between the engine (engine.cpp) and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "zly.h"
+
+namespace zly {
+
+typedef __bf16 bf16_t;
+
+// One frame as the preprocess/decode kernels see it.
+struct FrameDesc {
+    unsigned long long src_off;   // byte offset of the frame's first pixel in the source buffer
+    int w, h;                     // request width / height (REQUEST dims: used for box normalisation too)
+};
+
+// Implicit-GEMM convolution launch arguments.  All tensors are NHWC, batch-major; a tensor
+// "view" is a channel slice [co, co+C) of a buffer whose pixels are `cs` elements apart, which is
+// how C2f split / Concat cost nothing.
+struct ConvArgs {
+    const void* in;   int in_cs, in_co;
+    int H, W;                     // input spatial size
+    int Cin;                      // input channels as stored (multiple of 8)
+    const void* wgt;              // tiled [CoutPad/16][Kpad/KSTEP][16][KSTEP]
+    const float* bias;            // [CoutPad]
+    void* out;        int out_cs, out_co;
+    int Ho, Wo, Cout;
+    const void* res;  int res_cs, res_co;    // optional residual (added after the activation)
+    int stride, pad;
+    int K;                        // ks*ks*Cin
+    int nk;                       // Kpad / KSTEP
+    int M;                        // batch*Ho*Wo
+    int act;                      // 1 = SiLU
+    int out_f32;                  // 1 = write fp32 regardless of the activation dtype
+};
+
+struct ConvLaunch { int ks, ct, pt, fastk; };
+
+// kernels_conv.hip
+hipError_t launch_conv(int dtype, const ConvArgs& a, const ConvLaunch& cfg, hipStream_t s);
+void       conv_pick_config(int dtype, int ks, int cin, int cout_pad, int M, ConvLaunch* cfg);
+int        conv_kstep(int dtype);
+
+// kernels_misc.hip
+hipError_t launch_preprocess(int dtype, const uint8_t* src, const FrameDesc* desc, int n,
+                             void* out_nhwc8, float* out_nchw_f32, int tw, int th, hipStream_t s);
+hipError_t launch_nchw_to_nhwc8(int dtype, const float* in_nchw, void* out_nhwc8, int n, int tw, int th, hipStream_t s);
+hipError_t launch_sppf_pool(int dtype, void* buf, int cs, int c, int n, int H, int W, hipStream_t s);
+hipError_t launch_upsample2x(int dtype, const void* in, int in_cs, int in_co, void* out, int out_cs, int out_co,
+                             int C, int n, int H, int W, hipStream_t s);
+hipError_t launch_head(const float* logits, int cs, int nc, int n, int H, int W, int stride_px,
+                       float* head, int N_total, int anchor_off, hipStream_t s);
+hipError_t launch_tap_to_nchw(int dtype, const void* in, int cs, int co, int C, int H, int W, int idx, float* out, hipStream_t s);
+
+// kernels_post.hip
+struct Cand { float x, y, w, h; float conf; int cls; int anchor; int pad_; };   // 32 bytes
+hipError_t launch_decode(const float* head, int nc, int N, int n, const FrameDesc* desc, float conf_thr,
+                         Cand* cand, int* cand_count, hipStream_t s);
+hipError_t launch_nms(const Cand* cand, const int* cand_count, int N, int n, float iou_thr, int nc,
+                      Cand* scratch, void* slabs, int cap, uint32_t tag0, hipStream_t s);
+
+}  // namespace zly
