@@ -180,11 +180,11 @@ struct PlanBuilder {
     bool c2f(const std::string& p, View in, View out, int n, bool shortcut, int H, int W) {
         const int c = out.C / 2;
         const int cat = add_buffer(p + ".cat", H, W, (2 + n) * c);
-        const int tmp = add_buffer(p + ".tmp", H, W, c);
         if (!conv({p + ".cv1"}, in, View{cat, 0, 2 * c})) return false;
         for (int i = 0; i < n; ++i) {
             const View src{cat, (1 + i) * c, c};
             const std::string m = p + ".m." + std::to_string(i);
+            const int tmp = add_buffer(m + ".tmp", H, W, c);
             if (!conv({m + ".cv1"}, src, View{tmp, 0, c})) return false;
             if (!conv({m + ".cv2"}, View{tmp, 0, c}, View{cat, (2 + i) * c, c}, shortcut ? src : View{-1, 0, 0})) return false;
         }
