@@ -40,7 +40,7 @@ $(OUT)/libzly_plugin.so: $(HOST)/hip_inference_engine.cpp $(HOST)/hip_inference_
 	$(CXX) -O2 -std=c++17 -fPIC -shared -Iinclude -I$(HOST) -o $@ $(HOST)/hip_inference_engine.cpp -L$(OUT) -lzly -pthread -Wl,-rpath,'$$ORIGIN'
 
 $(OUT)/test_hip_engine: tests/cpp/test_hip_engine.cpp $(OUT)/libzly_plugin.so
-	$(CXX) -O2 -std=c++17 -Iinclude -I$(HOST) -o $@ tests/cpp/test_hip_engine.cpp -L$(OUT) -lzly_plugin -lzly -pthread -Wl,-rpath,'$$ORIGIN'
+	$(CXX) -O2 -std=c++17 -Iinclude -I$(HOST) -o $@ tests/cpp/test_hip_engine.cpp -Wl,--no-as-needed -L$(OUT) -lzly_plugin -lzly -pthread -Wl,-rpath,'$$ORIGIN'
 
 # ---- CPU oracle (test infrastructure only) --------------------------------------------------------
 oracle: oracle/_build/libzly_oracle.so

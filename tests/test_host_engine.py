@@ -1,0 +1,88 @@
+"""The drop-in host side: HipInferenceEngine behind the reference's IInferenceEngine plugin interface
+(zero-latency-yolo_amd/host), exercised by the C++ driver tests/cpp/test_hip_engine.cpp the way the
+reference's server uses an engine (InferenceEngineManager -> initialize -> setCallback -> submitInference)."""
+import json
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import zly_model as zm
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "zero-latency-yolo_amd", "_build", "test_hip_engine")
+
+
+def _ensure_bin():
+    if not os.path.exists(BIN):
+        subprocess.run(["make", "-C", ROOT, "host"], check=True, stdout=subprocess.DEVNULL)
+
+
+def _write_frames(path, frames, bad_index=None):
+    with open(path, "wb") as f:
+        f.write(struct.pack("<I", len(frames)))
+        for i, fr in enumerate(frames):
+            raw = np.ascontiguousarray(fr, dtype=np.uint8).tobytes()
+            if i == bad_index:
+                raw = raw[:-1]                                  # wrong byte count -> INVALID_INPUT for this frame only
+            f.write(struct.pack("<HHI", fr.shape[1], fr.shape[0], len(raw)))
+            f.write(raw)
+
+
+def test_plugin_registers_and_fails_loudly_without_gpu(tmp_path, weights_path):
+    """CPU-runnable: the factory registers under "hip" by static initialisation, submit before
+    initialize is NOT_INITIALIZED (3), and initialize() reports an error instead of simulating."""
+    _ensure_bin()
+    frames = tmp_path / "f.bin"
+    _write_frames(frames, [np.zeros((8, 8, 3), np.uint8)])
+    out = tmp_path / "o.json"
+    r = subprocess.run([BIN, weights_path, str(frames), str(out), "probe"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    j = json.loads(out.read_text())
+    assert j["available"] is True and j["name"] == "hip"
+    assert j["submit_before_init"] == 3
+    assert j["init_missing_model"] in (201, 300)                # 300 (no device) on a CPU-only host
+    assert j["init"] in (0, 300)
+
+
+@pytest.mark.gpu
+def test_host_engine_matches_c_abi_and_oracle(tmp_path, weights_path, oracle):
+    import zly
+    from oracle_lib import det_fields_equal
+    _ensure_bin()
+    frames = list(zm.synth_frames(9, 416, 416, seed=5, rects=False)) + [zm.synth_frames(1, 800, 600, seed=3, rects=False)[0],
+                                                                          zm.synth_frames(1, 320, 200, seed=4, rects=False)[0]]
+    bad = 4
+    fpath, out = tmp_path / "frames.bin", tmp_path / "out.json"
+    _write_frames(fpath, frames, bad_index=bad)
+    r = subprocess.run([BIN, weights_path, str(fpath), str(out)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    j = json.loads(out.read_text())
+    assert j["available"] and j["name"] == "hip" and j["init"] == 0
+    assert j["submit_before_init"] == 3 and j["submit_after_shutdown"] == 3 and j["init_missing_model"] == 201
+    res = j["results"]
+    good = [i for i in range(len(frames)) if i != bad]
+    assert [x["frame_id"] for x in res] == good                 # every good frame, once, in submission order
+    st = j["status"]
+    for key in ("name", "simulation_mode", "running", "model_path", "queue_size", "inference_count", "inference_errors",
+                "dropped_frames", "avg_inference_time_ms", "p99_inference_time_ms", "avg_preprocessing_time_ms",
+                "avg_postprocessing_time_ms", "worker_threads"):
+        assert key in st, key                                   # reference getStatus keys (onnx_engine.cpp:279-312)
+    assert st["inference_count"] == str(len(good)) and st["inference_errors"] == "1" and st["simulation_mode"] == "false"
+    assert j["queue_size_after"] == 0 and j["shutdown_ok"]
+
+    eng = zly.Engine(weights_path, max_batch=8, max_dets=256, warmup_runs=1)
+    for x in res:
+        i = x["frame_id"]
+        assert x["client_id"] == 1000 + i % 3 and x["timestamp"] == 777000 + i      # echoes the request (onnx_engine.cpp:520-521)
+        dets, n = eng.detect(frames[i], cap=256)
+        got = np.zeros(len(x["dets"]), dtype=zly.DET_DTYPE)
+        for k, d in enumerate(x["dets"]):
+            bits = np.array(d[:5], dtype=np.uint32).view(np.float32)
+            got[k] = (bits[0], bits[1], bits[2], bits[3], bits[4], d[5], d[6], 0, d[7])
+        assert len(got) == min(n, 256) and det_fields_equal(got, dets)
+        want = oracle.postprocess(eng.head_tensor(0), frames[i].shape[1], frames[i].shape[0])
+        assert det_fields_equal(got, want[:256])
+    eng.close()

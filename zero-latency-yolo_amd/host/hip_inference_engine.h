@@ -1,0 +1,87 @@
+// hip_inference_engine.h -- the reference's inference-engine plugin, MI355X-native.
+//
+// `HipInferenceEngine` implements zero_latency::IInferenceEngine (reference
+// src/inference/inference_engine.h:33-43) and `HipInferenceEngineFactory` registers it under the
+// name "hip", so the reference's server selects it with `"inference_engine": "hip"` in
+// configs/server.json (reference src/server/main.cpp:224-240).  It is the counterpart of
+// OnnxInferenceEngine (reference src/inference/onnx_engine.{h,cpp}) and only talks to the GPU
+// through the C ABI of include/zly.h.
+//
+// Behaviour kept from the reference:
+//   * submitInference returns NOT_INITIALIZED when the engine is not running (onnx_engine.cpp:224-226),
+//     copies the request and never blocks on inference (:233-258);
+//   * GameState.frame_id / timestamp echo the request (:520-521); the callback runs on an engine-owned
+//     thread, once per successful frame, and is not invoked for failed frames (:376-388);
+//   * getStatus() exposes the reference's keys (:279-312).
+// Deliberate differences (DESIGN.md "host side"):
+//   * every successful frame reaches the callback, in submission order (the reference drops frames
+//     popped by its worker threads, :459-460);
+//   * pending requests are batched into ONE zly_detect_batch call (the reference's "dynamic batching"
+//     is a TODO that runs frames one by one, :348-365) -- no batching window, so no added latency;
+//   * no simulation mode: a missing/bad model file is an error from initialize(), not random boxes
+//     (:70-75,105-110);
+//   * one worker thread per GPU (ZLY_NUM_DEVICES, default 1) instead of CPU worker threads.
+#pragma once
+
+#include "zly_compat.hpp"
+
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+
+struct zly_engine;
+
+namespace zero_latency {
+
+class HipInferenceEngine : public IInferenceEngine {
+public:
+    explicit HipInferenceEngine(const ServerConfig& config);
+    ~HipInferenceEngine() override;
+
+    Result<void> initialize() override;
+    Result<void> shutdown() override;
+    Result<void> submitInference(const InferenceRequest& request) override;
+    void setCallback(InferenceCallback callback) override;
+    size_t getQueueSize() const override;
+    std::string getName() const override;
+    std::unordered_map<std::string, std::string> getStatus() const override;
+
+private:
+    struct Pending { uint64_t seq; InferenceRequest request; uint64_t enqueue_ms; };
+    struct Done { uint32_t client_id; bool ok; GameState state; };
+
+    void workerLoop(int worker);
+    void emitInOrder(std::vector<std::pair<uint64_t, Done>>&& finished);
+
+    ServerConfig config_;
+    int max_batch_ = 8;
+    int max_dets_ = 256;
+    std::vector<zly_engine*> engines_;          // one per GPU
+    std::vector<std::thread> workers_;
+    std::atomic<bool> running_{false};
+
+    mutable std::mutex queue_mutex_;
+    std::condition_variable queue_cv_;
+    std::deque<Pending> queue_;
+    uint64_t next_seq_ = 0;
+
+    std::mutex emit_mutex_;
+    std::map<uint64_t, Done> finished_;
+    uint64_t next_emit_ = 0;
+    InferenceCallback callback_;
+
+    std::atomic<uint64_t> inference_count_{0}, inference_errors_{0}, dropped_frames_{0}, batches_{0};
+    std::atomic<size_t> queue_high_water_mark_{0};
+    mutable std::mutex stats_mutex_;
+    std::deque<double> latency_window_ms_;      // last 100 request latencies (onnx_engine.cpp:428-449)
+    double total_latency_ms_ = 0;
+};
+
+class HipInferenceEngineFactory : public IInferenceEngineFactory {
+public:
+    std::unique_ptr<IInferenceEngine> createEngine(const ServerConfig& config) override;
+    std::string getName() const override;
+};
+
+}  // namespace zero_latency
