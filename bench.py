@@ -140,6 +140,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the batch-64 / latency / roofline legs")
     ap.add_argument("--eager", action="store_true", help="no hipGraph replay")
+    ap.add_argument("--dump-ops", default="", help="write the per-op hipEvent profile (name, ms, GFLOP, GB, TFLOP/s, GB/s) to this file")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -234,6 +235,14 @@ def main():
                             "all_ops_ms_per_step": round(float(ms.sum()), 4),
                             "other_ops_ms": {o["name"]: round(float(m), 4) for o, m in zip(ops, ms) if o["kind"] != 1},
                             "slowest_convs_ms": {o["name"]: round(float(m), 4) for o, m in top}}
+                if a.dump_ops:
+                    with open(a.dump_ops, "a") as f:
+                        f.write(f"# batch {nb}: per-op mean ms over 20 eager reps (hipEvents around every launch)\n")
+                        f.write(f"{'op':44s} {'kind':>4s} {'ms':>9s} {'GFLOP':>9s} {'MB':>9s} {'TFLOP/s':>9s} {'GB/s':>9s}\n")
+                        for o, m in zip(ops, ms):
+                            gf, mb = o["flops"] * nb / 1e9, o["bytes"] * nb / 1e6
+                            f.write(f"{o['name']:44s} {o['kind']:4d} {m:9.4f} {gf:9.3f} {mb:9.2f} {gf / max(m, 1e-9):9.2f} {mb / max(m, 1e-9):9.1f}\n")
+                        f.write(f"{'TOTAL':44s} {'':4s} {float(ms.sum()):9.4f}\n\n")
             result["roofline"] = roof[B]
             result["roofline_b64"] = roof[big]
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

@@ -57,7 +57,11 @@ def test_host_engine_matches_c_abi_and_oracle(tmp_path, weights_path, oracle):
     bad = 4
     fpath, out = tmp_path / "frames.bin", tmp_path / "out.json"
     _write_frames(fpath, frames, bad_index=bad)
-    r = subprocess.run([BIN, weights_path, str(fpath), str(out)], capture_output=True, text=True, timeout=300)
+    # ZLY_MAX_BATCH=1: the plugin serves frame by frame, so its results are bit-comparable with single-frame
+    # zly_detect (with batching on, tile shapes -- and so bf16 roundings -- depend on how many requests
+    # happened to be pending; that mode is covered by test_host_engine_batches_pending_requests)
+    env = dict(os.environ, ZLY_MAX_BATCH="1")
+    r = subprocess.run([BIN, weights_path, str(fpath), str(out)], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr
     j = json.loads(out.read_text())
     assert j["available"] and j["name"] == "hip" and j["init"] == 0
@@ -86,3 +90,19 @@ def test_host_engine_matches_c_abi_and_oracle(tmp_path, weights_path, oracle):
         want = oracle.postprocess(eng.head_tensor(0), frames[i].shape[1], frames[i].shape[0])
         assert det_fields_equal(got, want[:256])
     eng.close()
+
+
+@pytest.mark.gpu
+def test_host_engine_batches_pending_requests(tmp_path, weights_path):
+    """default batching: a burst of 24 requests is served in fewer zly_detect_batch calls than frames,
+    every frame is still delivered exactly once and in submission order."""
+    _ensure_bin()
+    frames = list(zm.synth_frames(24, 416, 416, seed=9, rects=False))
+    fpath, out = tmp_path / "frames.bin", tmp_path / "out.json"
+    _write_frames(fpath, frames)
+    r = subprocess.run([BIN, weights_path, str(fpath), str(out)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    j = json.loads(out.read_text())
+    assert [x["frame_id"] for x in j["results"]] == list(range(24))
+    assert int(j["status"]["batches"]) < 24 and j["status"]["inference_count"] == "24"
+    assert sum(len(x["dets"]) for x in j["results"]) > 0

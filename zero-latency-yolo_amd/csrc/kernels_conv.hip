@@ -60,22 +60,38 @@ __device__ __forceinline__ f32x4 load4(const bf16_t* p) {
 __device__ __forceinline__ f32x4 load4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
 // MODE 0: 1x1 conv.  MODE 1: 3x3, Cin % KSTEP == 0 (a k-step never straddles a tap; tap/ci advance
-// incrementally).  MODE 2: 3x3, any Cin % EPL == 0 (per-step division).
-// One wave owns PT 16-pixel tiles x CT 16-channel tiles; a 256-thread workgroup is 4 waves on
-// consecutive pixel tiles of the same channel block (they share the weight fragments through L1).
-template <typename T, int MODE, int CT, int PT>
+// incrementally).  MODE 2: 3x3, any Cin % EPL == 0 (tap = k / Cin by reciprocal multiply).
+// One wave owns PT 16-pixel tiles x CT 16-channel tiles.
+// KSPLIT == 1: a 256-thread workgroup is 4 waves on consecutive pixel tiles of the same channel block
+//              (they share the weight fragments through L1); each wave walks the whole K.
+// KSPLIT == 4: the 4 waves share ONE set of pixel tiles and each walks a quarter of K; partial sums are
+//              reduced through LDS.  Used when M is small (batch 1, deep layers): 4x the workgroups and a
+//              4x shorter dependent load->MFMA chain, which is what bounds those launches.
+// The k-loop is software pipelined by hand: fragments of step s+1 are requested before the MFMAs of
+// step s issue (two named register sets, statically indexed).
+template <typename T, int MODE, int CT, int PT, int KSPLIT>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
 {
     typedef typename Frag<T>::type F;
     constexpr int EPL = Frag<T>::EPL;
     constexpr int KSTEP = Frag<T>::KSTEP;
+    constexpr int WTILE = 16 * KSTEP;
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int p = lane & 15;       // pixel within a 16-pixel tile (MFMA B column / D column)
     const int kq = lane >> 4;      // which 8-wide (4-wide for fp32) k group this lane feeds
-    const int m_base = (blockIdx.x * 4 + wave) * (PT * 16);
-    if (m_base >= a.M) return;     // wave-uniform; the kernel has no barriers
+    int m_base, s_begin, s_end;
+    if (KSPLIT == 1) {
+        m_base = (blockIdx.x * 4 + wave) * (PT * 16);
+        s_begin = 0; s_end = a.nk;
+        if (m_base >= a.M) return;     // wave-uniform; this variant has no barriers
+    } else {
+        m_base = blockIdx.x * (PT * 16);
+        const int per = (a.nk + KSPLIT - 1) / KSPLIT;
+        s_begin = wave * per;
+        s_end = min(a.nk, s_begin + per);
+    }
 
     const T* __restrict__ in = static_cast<const T*>(a.in);
 
@@ -101,31 +117,32 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
 #pragma unroll
         for (int t = 0; t < PT; ++t) acc[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    constexpr int WTILE = 16 * KSTEP;
     const T* __restrict__ wp = static_cast<const T*>(a.wgt) +
                                (size_t)(blockIdx.y * CT) * a.nk * WTILE + p * KSTEP + kq * EPL;
 
-    int tap = 0, cbase = 0;        // MODE 1 running position
-    for (int s = 0; s < a.nk; ++s) {
-        F wf[CT];
+    // MODE 1 running position of the NEXT step to be loaded (wave-uniform)
+    int tap = 0, cbase = 0;
+    if (MODE == 1) { const int k0 = s_begin * KSTEP; tap = k0 / a.Cin; cbase = k0 - tap * a.Cin; }
+    const float inv_cin = 1.0f / (float)a.Cin;
+
+    auto load_step = [&](int s, F (&wf)[CT], F (&af)[PT]) {
 #pragma unroll
         for (int c = 0; c < CT; ++c)
             wf[c] = *reinterpret_cast<const F*>(wp + ((size_t)c * a.nk + s) * WTILE);
-
         int ci, ky, kx;
         bool kval;
         if (MODE == 0) {
             ci = s * KSTEP + kq * EPL; ky = 0; kx = 0; kval = ci < a.Cin;
         } else if (MODE == 1) {
             ci = cbase + kq * EPL; ky = tap / 3; kx = tap - ky * 3; kval = true;
+            cbase += KSTEP;
+            if (cbase == a.Cin) { cbase = 0; ++tap; }
         } else {
             const int k = s * KSTEP + kq * EPL;
-            const int tp = k / a.Cin;
+            const int tp = (int)(((float)k + 0.5f) * inv_cin);      // exact for k < 2^20: frac(k/Cin) >= 1/Cin
             ci = k - tp * a.Cin; ky = tp / 3; kx = tp - ky * 3; kval = tp < 9;
         }
         const int koff = (ky * a.W + kx) * a.in_cs + ci;
-
-        F af[PT];
 #pragma unroll
         for (int t = 0; t < PT; ++t) {
             const int iy = iy0[t] + ky, ix = ix0[t] + kx;
@@ -135,15 +152,46 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
             for (int j = 0; j < EPL; ++j) z[j] = (T)0.0f;
             af[t] = ok ? *reinterpret_cast<const F*>(in + (long)(boff[t] + koff)) : z;
         }
+    };
+    auto mma_all = [&](const F (&wf)[CT], const F (&af)[PT]) {
 #pragma unroll
         for (int c = 0; c < CT; ++c)
 #pragma unroll
             for (int t = 0; t < PT; ++t) acc[c][t] = mma_step(wf[c], af[t], acc[c][t]);
+    };
 
-        if (MODE == 1) {
-            cbase += KSTEP;
-            if (cbase == a.Cin) { cbase = 0; ++tap; }
+    F wfA[CT], afA[PT], wfB[CT], afB[PT];
+    if (s_begin < s_end) load_step(s_begin, wfA, afA);
+    for (int s = s_begin; s < s_end; s += 2) {
+        if (s + 1 < s_end) load_step(s + 1, wfB, afB);
+        mma_all(wfA, afA);
+        if (s + 2 < s_end) load_step(s + 2, wfA, afA);
+        if (s + 1 < s_end) mma_all(wfB, afB);
+    }
+
+    if constexpr (KSPLIT > 1) {
+        // partial sums of waves 1..3 -> LDS -> wave 0 (each lane only ever touches its own column)
+        __shared__ float red[(KSPLIT - 1) * CT * PT * 4 * 64];
+        if (wave > 0) {
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int t = 0; t < PT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        red[(((wave - 1) * CT + c) * PT + t) * 256 + r * 64 + lane] = acc[c][t][r];
         }
+        __syncthreads();
+        if (wave > 0) return;
+#pragma unroll
+        for (int w = 0; w < KSPLIT - 1; ++w)
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int t = 0; t < PT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        acc[c][t][r] += red[((w * CT + c) * PT + t) * 256 + r * 64 + lane];
     }
 
     // epilogue: lane holds channels ch..ch+3 of pixel m for every (c, t)
@@ -173,54 +221,80 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
 
 typedef void (*conv_fn)(const ConvArgs);
 
-template <typename T, int MODE, int PT>
+template <typename T, int MODE, int PT, int KSPLIT>
 static conv_fn pick_ct(int ct) {
     switch (ct) {
-        case 1: return conv_igemm_kernel<T, MODE, 1, PT>;
-        case 2: return conv_igemm_kernel<T, MODE, 2, PT>;
-        case 3: return conv_igemm_kernel<T, MODE, 3, PT>;
-        case 4: return conv_igemm_kernel<T, MODE, 4, PT>;
-        case 5: return conv_igemm_kernel<T, MODE, 5, PT>;
+        case 1: return conv_igemm_kernel<T, MODE, 1, PT, KSPLIT>;
+        case 2: return conv_igemm_kernel<T, MODE, 2, PT, KSPLIT>;
+        case 3: return conv_igemm_kernel<T, MODE, 3, PT, KSPLIT>;
+        case 4: return conv_igemm_kernel<T, MODE, 4, PT, KSPLIT>;
+        case 5: return conv_igemm_kernel<T, MODE, 5, PT, KSPLIT>;
     }
     return nullptr;
 }
-template <typename T, int PT>
+template <typename T, int PT, int KSPLIT>
 static conv_fn pick_mode(int mode, int ct) {
     switch (mode) {
-        case 0: return pick_ct<T, 0, PT>(ct);
-        case 1: return pick_ct<T, 1, PT>(ct);
-        case 2: return pick_ct<T, 2, PT>(ct);
+        case 0: return pick_ct<T, 0, PT, KSPLIT>(ct);
+        case 1: return pick_ct<T, 1, PT, KSPLIT>(ct);
+        case 2: return pick_ct<T, 2, PT, KSPLIT>(ct);
     }
     return nullptr;
 }
 
 int conv_kstep(int dtype) { return dtype == ZLY_DTYPE_BF16 ? Frag<bf16_t>::KSTEP : Frag<float>::KSTEP; }
 
+// Tile shape per launch.  The chip has 256 CUs; a launch wants >= ~2 workgroups per CU.
+//   large M (batch 64, shallow layers): PT = 4 / 2 pixel tiles per wave amortise the weight fragments;
+//   small M (batch 1, deep layers): PT = 1, fewer channel tiles per wave and 4-way split-K, so that
+//   even the 13x13 layers put a few hundred workgroups on the chip.
 void conv_pick_config(int dtype, int ks, int cin, int cout_pad, int M, ConvLaunch* cfg)
 {
     const int kstep = conv_kstep(dtype);
     cfg->ks = ks;
     cfg->fastk = (ks == 3 && cin % kstep == 0) ? 1 : 0;
+    cfg->ksplit = 1;
     const int ntiles = cout_pad / 16;
     static const int pref[5] = {4, 5, 3, 2, 1};
     cfg->ct = 1;
     for (int i = 0; i < 5; ++i)
         if (ntiles % pref[i] == 0) { cfg->ct = pref[i]; break; }
-    // two pixel tiles per wave only once the grid would still hold >= 4 workgroups per CU
-    const long wgs_pt2 = ((long)(M + 127) / 128) * (ntiles / cfg->ct);
-    cfg->pt = (dtype == ZLY_DTYPE_BF16 && wgs_pt2 < 1024) ? 1 : 2;
+    if (dtype != ZLY_DTYPE_BF16) { cfg->pt = 2; return; }           // fp32 = verification mode: one shape
+    const long ytiles = ntiles / cfg->ct;
+    const long wgs_pt4 = ((long)(M + 255) / 256) * ytiles;
+    const long wgs_pt2 = ((long)(M + 127) / 128) * ytiles;
+    const long wgs_pt1 = ((long)(M + 63) / 64) * ytiles;
+    if (wgs_pt4 >= 1024 && cfg->ct <= 4) { cfg->pt = 4; return; }       // CT=5 x PT=4 would need > 200 VGPRs
+    if (wgs_pt2 >= 1024) { cfg->pt = 2; return; }
+    cfg->pt = 1;
+    const int nk = (ks * ks * cin + kstep - 1) / kstep;
+    if (wgs_pt1 >= 512 || nk < 4) return;
+    cfg->ksplit = 4;                                                 // workgroup = one 16-pixel tile
+    long wgs = ((long)(M + 15) / 16) * ytiles;
+    while (wgs < 256 && cfg->ct > 1) {                               // still thin: fewer channel tiles per wave
+        int nct = cfg->ct - 1;
+        while (nct > 1 && ntiles % nct != 0) --nct;
+        cfg->ct = nct;
+        wgs = ((long)(M + 15) / 16) * (ntiles / cfg->ct);
+    }
 }
 
 hipError_t launch_conv(int dtype, const ConvArgs& a, const ConvLaunch& cfg, hipStream_t s)
 {
     const int mode = cfg.ks == 1 ? 0 : (cfg.fastk ? 1 : 2);
     conv_fn fn = nullptr;
-    if (dtype == ZLY_DTYPE_BF16) fn = cfg.pt == 1 ? pick_mode<bf16_t, 1>(mode, cfg.ct) : pick_mode<bf16_t, 2>(mode, cfg.ct);
-    else                         fn = pick_mode<float, 2>(mode, cfg.ct);
+    if (dtype == ZLY_DTYPE_BF16) {
+        if (cfg.ksplit == 4)   fn = pick_mode<bf16_t, 1, 4>(mode, cfg.ct);
+        else if (cfg.pt == 1)  fn = pick_mode<bf16_t, 1, 1>(mode, cfg.ct);
+        else if (cfg.pt == 2)  fn = pick_mode<bf16_t, 2, 1>(mode, cfg.ct);
+        else                   fn = pick_mode<bf16_t, 4, 1>(mode, cfg.ct);
+    } else {
+        fn = pick_mode<float, 2, 1>(mode, cfg.ct);
+    }
     if (!fn) return hipErrorInvalidValue;
     const int cout_pad = (a.Cout + 15) / 16 * 16;
     const int ytiles = cout_pad / (16 * cfg.ct);
-    const int px_per_wg = 64 * cfg.pt;
+    const int px_per_wg = cfg.ksplit == 4 ? 16 * cfg.pt : 64 * cfg.pt;
     dim3 grid((a.M + px_per_wg - 1) / px_per_wg, ytiles, 1);
     hipLaunchKernelGGL(fn, grid, dim3(256), 0, s, a);
     return hipGetLastError();

@@ -35,7 +35,7 @@ struct ConvArgs {
     int out_f32;                  // 1 = write fp32 regardless of the activation dtype
 };
 
-struct ConvLaunch { int ks, ct, pt, fastk; };
+struct ConvLaunch { int ks, ct, pt, fastk, ksplit; };
 
 // kernels_conv.hip
 hipError_t launch_conv(int dtype, const ConvArgs& a, const ConvLaunch& cfg, hipStream_t s);
