@@ -331,7 +331,7 @@ static hipError_t run_op(zly_engine* e, const Op& op, int n, const uint8_t* d_sr
         a.stride = op.stride; a.pad = op.ks / 2;
         a.K = op.K; a.nk = op.nk; a.M = n * ob.H * ob.W; a.act = op.act; a.out_f32 = op.out_f32;
         ConvLaunch cfg;
-        conv_pick_config(e->dtype, op.ks, op.in.C, op.cout_pad, a.M, &cfg);
+        conv_pick_config(e->dtype, op.ks, op.stride, op.in.C, op.cout_pad, n, ob.H, ob.W, &cfg);
         return launch_conv(e->dtype, a, cfg, s);
     }
     case OP_SPPF: {
@@ -495,6 +495,7 @@ int32_t zly_create(const zly_config* cfg, zly_engine** out)
         return fail(ZLY_ERR_SYSTEM, "no HIP device available: this engine has no CPU fallback");
     if (cfg->device < 0 || cfg->device >= ndev) return fail(ZLY_ERR_INVALID_ARGUMENT, "device ordinal out of range");
     HIP_TRY(hipSetDevice(cfg->device), ZLY_ERR_SYSTEM);
+    HIP_TRY(conv_init(), ZLY_ERR_SYSTEM);
 
     zly_engine* e = new zly_engine();
     e->cfg = *cfg;

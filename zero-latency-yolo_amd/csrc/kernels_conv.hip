@@ -10,8 +10,9 @@
 //     NHWC store -- the transposed assignment would scatter 2-byte stores.
 //   * NHWC makes the 8 k-values a lane needs (8 consecutive input channels of one tap) one 16-byte
 //     load, so fragments come straight from global memory: no im2col buffer, no LDS round trip.
-//   * weights are pre-tiled on the host as [cout/16][k/KSTEP][16][KSTEP], so one weight fragment for
-//     the whole wave is one contiguous 1 KiB read (weights.cpp: repack_conv).
+//   * weights are pre-tiled on the host as [cout/16][k/KSTEP][lane = kq*16 + row][EPL], i.e. each 1 KiB
+//     tile is stored in MFMA lane order: one weight fragment for the whole wave is one contiguous
+//     1 KiB read from global memory and a conflict-free ds_read_b128 from LDS (weights.cpp: repack_conv).
 //   * bias + SiLU + optional residual add + write-at-channel-offset (free Concat / split) are fused
 //     into the epilogue.
 // fp32 mode uses v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain) with a permuted k order inside each
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
         for (int t = 0; t < PT; ++t) acc[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const T* __restrict__ wp = static_cast<const T*>(a.wgt) +
-                               (size_t)(blockIdx.y * CT) * a.nk * WTILE + p * KSTEP + kq * EPL;
+                               (size_t)(blockIdx.y * CT) * a.nk * WTILE + lane * EPL;
 
     // MODE 1 running position of the NEXT step to be loaded (wave-uniform)
     int tap = 0, cbase = 0;
@@ -219,6 +220,204 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 3x3 convolution, LDS-tiled (bf16, Cin % 32 == 0, pad 1, stride S): the throughput kernel.
+//
+// The direct kernel above re-reads every input pixel 9x (once per tap) and the whole weight matrix once
+// per 16 pixels through L1; at batch 64 that traffic, not MFMA or HBM, bounds it.  Here a workgroup owns
+// a TH x 16 output tile of one frame and walks Cin in chunks of 32 channels.  Per chunk it stages
+//   * the input patch ((TH-1)S+3) x (15S+3) pixels x 32 ch  -> LDS, pixel pitch 96 B (S=1) / 80 B (S=2):
+//     conflict-free for the ds_read_b128 fragment pattern (tests/lds_pitch.py), zero-filled outside the frame
+//   * the 9 x CT weight tiles (1 KiB each, already in MFMA lane order)                     -> LDS
+// once, and all 9 taps x CT x PT MFMAs of the 4 waves read their fragments from LDS.
+// Workgroups are persistent over (tile, chunk) items: the global loads of item i+1 are issued into
+// registers before the MFMAs of item i and written to LDS after them (one LDS buffer, so two
+// workgroups fit per CU and cover each other's barriers).
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+template <int S, int PT> struct LdsGeom {
+    static constexpr int TH = 4 * PT, TW = 16;
+    static constexpr int PH = (TH - 1) * S + 3, PW = (TW - 1) * S + 3;
+    static constexpr int PITCH = S == 1 ? 96 : 80;
+    static constexpr int PATCH_BYTES = (PH * PW * PITCH + 15) / 16 * 16;
+};
+
+template <int S, int CT, int PT>
+__global__ __launch_bounds__(256) void conv3x3_lds_kernel(const ConvArgs a, int tiles_x, int tiles_per_img, int total_tiles)
+{
+    typedef LdsGeom<S, PT> G;
+    constexpr int PW = G::PW, PITCH = G::PITCH;
+    constexpr int NPU = G::PH * G::PW * 4;            // 16-byte units in the patch chunk
+    constexpr int NPU_T = (NPU + 255) / 256;
+    constexpr int NWU = 9 * CT * 64;                  // 16-byte units in the weight chunk
+    constexpr int NWU_T = (NWU + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* lpatch = smem;
+    unsigned char* lw = smem + G::PATCH_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p = lane & 15, kq = lane >> 4;
+    const int nchunks = a.Cin >> 5;
+    const bf16_t* __restrict__ in = static_cast<const bf16_t*>(a.in) + a.in_co;
+    const bf16_t* __restrict__ wbase = static_cast<const bf16_t*>(a.wgt) + (size_t)(blockIdx.y * CT) * a.nk * 512;
+
+    int tile = blockIdx.x;
+    if (tile >= total_tiles) return;
+    int chunk = 0;
+
+    u32x4 rp[NPU_T], rw[NWU_T];
+    auto stage_load = [&](int tl, int c) {
+        const int b = tl / tiles_per_img;
+        const int r = tl - b * tiles_per_img;
+        const int ty = r / tiles_x, tx = r - ty * tiles_x;
+        const int iy_base = ty * G::TH * S - 1, ix_base = tx * G::TW * S - 1;
+        const bf16_t* inb = in + (size_t)b * a.H * a.W * a.in_cs + c * 32;
+#pragma unroll
+        for (int i = 0; i < NPU_T; ++i) {
+            const int u = tid + i * 256;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (u < NPU) {
+                const int px = u >> 2, q = u & 3;
+                const int py = px / PW, pxx = px - py * PW;
+                const int iy = iy_base + py, ix = ix_base + pxx;
+                if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+                    v = *reinterpret_cast<const u32x4*>(inb + ((size_t)iy * a.W + ix) * a.in_cs + q * 8);
+            }
+            rp[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < NWU_T; ++i) {
+            const int u = tid + i * 256;
+            if (u < NWU) {
+                const int ti = u >> 6, l = u & 63;             // ti = tap * CT + ct
+                const int t = ti / CT, ct = ti - t * CT;
+                rw[i] = *reinterpret_cast<const u32x4*>(wbase + ((size_t)ct * a.nk + t * nchunks + c) * 512 + l * 8);
+            }
+        }
+    };
+    auto stage_store = [&]() {
+#pragma unroll
+        for (int i = 0; i < NPU_T; ++i) {
+            const int u = tid + i * 256;
+            if (u < NPU) *reinterpret_cast<u32x4*>(lpatch + (u >> 2) * PITCH + (u & 3) * 16) = rp[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NWU_T; ++i) {
+            const int u = tid + i * 256;
+            if (u < NWU) *reinterpret_cast<u32x4*>(lw + u * 16) = rw[i];
+        }
+    };
+
+    f32x4 acc[CT][PT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int t = 0; t < PT; ++t) acc[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    stage_load(tile, 0);
+    while (true) {
+        stage_store();
+        __syncthreads();
+        int ntile = tile, nchunk = chunk + 1;
+        if (nchunk == nchunks) { nchunk = 0; ntile = tile + gridDim.x; }
+        const bool has_next = ntile < total_tiles;
+        if (has_next) stage_load(ntile, nchunk);          // lands in registers while the MFMAs below run
+
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int ky = t / 3, kx = t - ky * 3;
+            bf16x8 wf[CT], af[PT];
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+                wf[c] = *reinterpret_cast<const bf16x8*>(lw + (t * CT + c) * 1024 + lane * 16);
+#pragma unroll
+            for (int i = 0; i < PT; ++i) {
+                const int row = wave * PT + i;
+                af[i] = *reinterpret_cast<const bf16x8*>(lpatch + ((row * S + ky) * PW + p * S + kx) * PITCH + kq * 16);
+            }
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int i = 0; i < PT; ++i) acc[c][i] = mma_step(wf[c], af[i], acc[c][i]);
+        }
+
+        if (chunk == nchunks - 1) {
+            // epilogue for `tile`: lane holds channels ch..ch+3 of pixel (oy, ox)
+            const int b = tile / tiles_per_img;
+            const int r = tile - b * tiles_per_img;
+            const int ty = r / tiles_x, tx = r - ty * tiles_x;
+            const int ox = tx * G::TW + p;
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                const int ch = (blockIdx.y * CT + c) * 16 + kq * 4;
+                const bool chok = ch < a.Cout;
+                const f32x4 bias = chok ? *reinterpret_cast<const f32x4*>(a.bias + ch) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < PT; ++i) {
+                    const int oy = ty * G::TH + wave * PT + i;
+                    f32x4 v = acc[c][i] + bias;
+                    acc[c][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (!chok || oy >= a.Ho || ox >= a.Wo) continue;
+                    const size_t m = ((size_t)b * a.Ho + oy) * a.Wo + ox;
+                    if (a.act) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] = silu<bf16_t>(v[q]);
+                    }
+                    if (a.res) v += load4(static_cast<const bf16_t*>(a.res) + m * a.res_cs + a.res_co + ch);
+                    if (a.out_f32) store4(static_cast<float*>(a.out) + m * a.out_cs + a.out_co + ch, v);
+                    else           store4(static_cast<bf16_t*>(a.out) + m * a.out_cs + a.out_co + ch, v);
+                }
+            }
+        }
+        __syncthreads();                                    // every wave is done reading this chunk's LDS image
+        if (!has_next) break;
+        tile = ntile;
+        chunk = nchunk;
+    }
+}
+
+typedef void (*conv_lds_fn)(const ConvArgs, int, int, int);
+
+template <int S, int PT>
+static conv_lds_fn pick_lds_ct(int ct) {
+    switch (ct) {
+        case 2: return conv3x3_lds_kernel<S, 2, PT>;
+        case 3: return conv3x3_lds_kernel<S, 3, PT>;
+        case 4: return conv3x3_lds_kernel<S, 4, PT>;
+        case 5: return conv3x3_lds_kernel<S, 5, PT>;
+    }
+    return nullptr;
+}
+static conv_lds_fn pick_lds(int stride, int pt, int ct) {
+    if (stride == 1) return pt == 1 ? pick_lds_ct<1, 1>(ct) : pt == 2 ? pick_lds_ct<1, 2>(ct) : pick_lds_ct<1, 4>(ct);
+    return pt == 1 ? pick_lds_ct<2, 1>(ct) : pick_lds_ct<2, 2>(ct);
+}
+static size_t lds_bytes(int stride, int pt, int ct) {
+    size_t patch = 0;
+    if (stride == 1) patch = pt == 1 ? LdsGeom<1, 1>::PATCH_BYTES : pt == 2 ? LdsGeom<1, 2>::PATCH_BYTES : LdsGeom<1, 4>::PATCH_BYTES;
+    else             patch = pt == 1 ? LdsGeom<2, 1>::PATCH_BYTES : LdsGeom<2, 2>::PATCH_BYTES;
+    return patch + (size_t)9 * ct * 1024;
+}
+
+// dynamic LDS above 64 KiB needs an opt-in per kernel; done once, outside any stream capture
+hipError_t conv_init()
+{
+    static const int pts1[3] = {1, 2, 4}, pts2[2] = {1, 2};
+    for (int ct = 2; ct <= 5; ++ct) {
+        for (int i = 0; i < 3; ++i) {
+            hipError_t r = hipFuncSetAttribute((const void*)pick_lds(1, pts1[i], ct), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(1, pts1[i], ct));
+            if (r != hipSuccess) return r;
+        }
+        for (int i = 0; i < 2; ++i) {
+            hipError_t r = hipFuncSetAttribute((const void*)pick_lds(2, pts2[i], ct), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(2, pts2[i], ct));
+            if (r != hipSuccess) return r;
+        }
+    }
+    return hipSuccess;
+}
+
 typedef void (*conv_fn)(const ConvArgs);
 
 template <typename T, int MODE, int PT, int KSPLIT>
@@ -242,13 +441,44 @@ static conv_fn pick_mode(int mode, int ct) {
     return nullptr;
 }
 
+void conv_pick_direct(int dtype, int ks, int cin, int cout_pad, int M, ConvLaunch* cfg);
+
 int conv_kstep(int dtype) { return dtype == ZLY_DTYPE_BF16 ? Frag<bf16_t>::KSTEP : Frag<float>::KSTEP; }
 
 // Tile shape per launch.  The chip has 256 CUs; a launch wants >= ~2 workgroups per CU.
 //   large M (batch 64, shallow layers): PT = 4 / 2 pixel tiles per wave amortise the weight fragments;
 //   small M (batch 1, deep layers): PT = 1, fewer channel tiles per wave and 4-way split-K, so that
 //   even the 13x13 layers put a few hundred workgroups on the chip.
-void conv_pick_config(int dtype, int ks, int cin, int cout_pad, int M, ConvLaunch* cfg)
+// LDS-tiled 3x3 kernel when the launch is big enough to fill the chip with TH x 16 tiles
+static bool pick_lds_config(int stride, int cin, int cout_pad, int n, int Ho, int Wo, ConvLaunch* cfg)
+{
+    if (cin % 32 != 0) return false;
+    const int ntiles = cout_pad / 16;
+    int ct = 0;
+    static const int pref[4] = {4, 5, 3, 2};
+    for (int i = 0; i < 4; ++i)
+        if (ntiles % pref[i] == 0) { ct = pref[i]; break; }
+    if (!ct) return false;
+    const int ytiles = ntiles / ct;
+    const int tx = (Wo + 15) / 16;
+    int pt = stride == 1 ? 2 : 1;
+    if (stride == 1 && ct == 2 && (long)n * tx * ((Ho + 15) / 16) * ytiles >= 2048) pt = 4;   // plenty of tiles, few channels: bigger tiles (VGPR budget)
+    if (stride == 1 && Ho <= 14) pt = 1;                                            // 13-row maps: 4 x 4 rows
+    const long tiles = (long)n * tx * ((Ho + 4 * pt - 1) / (4 * pt));
+    if (tiles * ytiles < 384) return false;                                         // too small: direct kernel
+    cfg->lds = 1; cfg->ct = ct; cfg->pt = pt; cfg->ksplit = 1; cfg->fastk = 1;
+    return true;
+}
+
+void conv_pick_config(int dtype, int ks, int stride, int cin, int cout_pad, int n, int Ho, int Wo, ConvLaunch* cfg)
+{
+    const int M = n * Ho * Wo;
+    cfg->ks = ks; cfg->lds = 0;
+    if (dtype == ZLY_DTYPE_BF16 && ks == 3 && pick_lds_config(stride, cin, cout_pad, n, Ho, Wo, cfg)) return;
+    conv_pick_direct(dtype, ks, cin, cout_pad, M, cfg);
+}
+
+void conv_pick_direct(int dtype, int ks, int cin, int cout_pad, int M, ConvLaunch* cfg)
 {
     const int kstep = conv_kstep(dtype);
     cfg->ks = ks;
@@ -259,6 +489,7 @@ void conv_pick_config(int dtype, int ks, int cin, int cout_pad, int M, ConvLaunc
     cfg->ct = 1;
     for (int i = 0; i < 5; ++i)
         if (ntiles % pref[i] == 0) { cfg->ct = pref[i]; break; }
+    cfg->lds = 0;
     if (dtype != ZLY_DTYPE_BF16) { cfg->pt = 2; return; }           // fp32 = verification mode: one shape
     const long ytiles = ntiles / cfg->ct;
     const long wgs_pt4 = ((long)(M + 255) / 256) * ytiles;
@@ -281,6 +512,22 @@ void conv_pick_config(int dtype, int ks, int cin, int cout_pad, int M, ConvLaunc
 
 hipError_t launch_conv(int dtype, const ConvArgs& a, const ConvLaunch& cfg, hipStream_t s)
 {
+    if (cfg.lds) {
+        conv_lds_fn fn = pick_lds(a.stride, cfg.pt, cfg.ct);
+        if (!fn || dtype != ZLY_DTYPE_BF16) return hipErrorInvalidValue;
+        const int cout_pad = (a.Cout + 15) / 16 * 16;
+        const int ytiles = cout_pad / (16 * cfg.ct);
+        const int th = 4 * cfg.pt;
+        const int tiles_x = (a.Wo + 15) / 16, tiles_y = (a.Ho + th - 1) / th;
+        const int n = a.M / (a.Ho * a.Wo);
+        const int tiles_per_img = tiles_x * tiles_y, total = tiles_per_img * n;
+        int gx = total;
+        const int max_wgs = 2 * 256;                       // two resident workgroups per CU
+        if (gx * ytiles > max_wgs) gx = (max_wgs + ytiles - 1) / ytiles;
+        if (gx > total) gx = total;
+        hipLaunchKernelGGL(fn, dim3(gx, ytiles, 1), dim3(256), lds_bytes(a.stride, cfg.pt, cfg.ct), s, a, tiles_x, tiles_per_img, total);
+        return hipGetLastError();
+    }
     const int mode = cfg.ks == 1 ? 0 : (cfg.fastk ? 1 : 2);
     conv_fn fn = nullptr;
     if (dtype == ZLY_DTYPE_BF16) {

@@ -100,6 +100,7 @@ void repack_conv(const std::vector<const ConvRec*>& srcs, int cin_store, int kst
     const int K = ks * ks * cin_store;
     const int nkk = (K + kstep - 1) / kstep;
     const size_t esz = bf16 ? 2 : 4;
+    const int epl = 16 / (int)esz;                 // elements per 16-byte fragment
     w_out->assign((size_t)cpad * nkk * kstep * esz, 0);
     bias_out->assign((size_t)cpad, 0.0f);
     int co_base = 0;
@@ -113,7 +114,8 @@ void repack_conv(const std::vector<const ConvRec*>& srcs, int cin_store, int kst
                     for (int ci = 0; ci < cin; ++ci) {
                         const int k = (ky * ks + kx) * cin_store + ci;
                         const int st = k / kstep, kk = k % kstep;
-                        const size_t dst = (((size_t)ct * nkk + st) * 16 + r) * kstep + kk;
+                        // 1 KiB tile in MFMA lane order: lane = (kk / epl) * 16 + r holds epl consecutive k
+                        const size_t dst = ((size_t)ct * nkk + st) * 16 * kstep + ((size_t)(kk / epl) * 16 + r) * epl + kk % epl;
                         const float v = s->w[(((size_t)co * cin + ci) * ks + ky) * ks + kx];
                         if (bf16) {
                             const uint16_t h = f32_to_bf16_rne(v);

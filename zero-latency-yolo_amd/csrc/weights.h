@@ -27,7 +27,8 @@ int load_zlyw(const char* path, ModelFile* out, std::string* err);
 uint16_t f32_to_bf16_rne(float f);
 
 // Concatenates `srcs` along cout and lays the result out as the conv kernel reads it:
-//   [cout_pad/16][nk][16][kstep] with k = (ky*ks + kx)*cin_store + ci, zero padded.
+//   [cout_pad/16][nk][lane = (kk/epl)*16 + row][epl] with k = (ky*ks + kx)*cin_store + ci = step*kstep + kk,
+//   zero padded: every 1 KiB tile is stored in MFMA lane order.
 // cin_store is the channel count of the activation tensor the conv reads (>= cin; the stem reads an
 // 8-channel tensor for its 3 input channels).  bf16 -> 2-byte elements, else fp32.
 void repack_conv(const std::vector<const ConvRec*>& srcs, int cin_store, int kstep, bool bf16,

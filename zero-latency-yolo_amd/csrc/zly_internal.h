@@ -35,11 +35,12 @@ struct ConvArgs {
     int out_f32;                  // 1 = write fp32 regardless of the activation dtype
 };
 
-struct ConvLaunch { int ks, ct, pt, fastk, ksplit; };
+struct ConvLaunch { int ks, ct, pt, fastk, ksplit, lds; };
 
 // kernels_conv.hip
 hipError_t launch_conv(int dtype, const ConvArgs& a, const ConvLaunch& cfg, hipStream_t s);
-void       conv_pick_config(int dtype, int ks, int cin, int cout_pad, int M, ConvLaunch* cfg);
+void       conv_pick_config(int dtype, int ks, int stride, int cin, int cout_pad, int n, int Ho, int Wo, ConvLaunch* cfg);
+hipError_t conv_init();
 int        conv_kstep(int dtype);
 
 // kernels_misc.hip
