@@ -55,6 +55,9 @@ extern "C" {
 #define ZLY_DTYPE_FP32 0   /* fp32 activations + exact-fp32 MFMA: verification mode */
 #define ZLY_DTYPE_BF16 1   /* bf16 activations/weights, fp32 accumulate: production mode */
 
+#define ZLY_FLAG_DUMP_LOGITS 1   /* also write the fp32 logits of the six final Detect convs (debug taps
+                                   "model.22.cv2.L.2" / "model.22.cv3.L.2"); off in production */
+
 typedef struct zly_engine zly_engine;
 
 /* Layout-identical to zero_latency::Detection: box{x,y,width,height}@0 (centre-x, centre-y, w, h,
@@ -92,6 +95,7 @@ typedef struct zly_config {
     int32_t dtype;              /* ZLY_DTYPE_* */
     int32_t warmup_runs;        /* warmupModel analogue, onnx_engine.cpp:919-954 (reference: 3) */
     int32_t use_graph;          /* 1: replay the forward as a hipGraph per batch size */
+    int32_t flags;              /* ZLY_FLAG_* */
 } zly_config;
 
 typedef struct zly_stats {
@@ -103,7 +107,7 @@ typedef struct zly_stats {
 
 typedef struct zly_op_info {
     char name[48];
-    int32_t kind;          /* 0 preprocess, 1 conv, 2 sppf-pool, 3 upsample, 4 head, 5 decode, 6 nms */
+    int32_t kind;          /* 0 preprocess, 1 conv, 2 sppf-pool, 3 upsample, 4 fused detect head (+decode), 6 nms */
     int32_t pad_;
     double flops_per_frame;   /* 2*MAC, algorithmic */
     double bytes_per_frame;   /* algorithmic: input read once + output written once + weights */

@@ -14,7 +14,7 @@ def main():
     nf = int(sys.argv[2]) if len(sys.argv) > 2 else 2
     wp = zly.DEFAULT_WEIGHTS
     ref = yolov8_ref.load(wp, mode)
-    eng = zly.Engine(wp, dtype=zly.DTYPE_FP32 if mode == "fp32" else zly.DTYPE_BF16, max_batch=nf, max_dets=512, use_graph=False)
+    eng = zly.Engine(wp, dtype=zly.DTYPE_FP32 if mode == "fp32" else zly.DTYPE_BF16, max_batch=nf, max_dets=512, use_graph=False, flags=zly.FLAG_DUMP_LOGITS)
     orc = Oracle()
     frames = zm.synth_frames(nf, 416, 416, seed=5, rects=False)
     x = np.stack([orc.preprocess(f, 416, 416)[1] for f in frames])

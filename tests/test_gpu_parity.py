@@ -31,7 +31,7 @@ F6 = ["x", "y", "w", "h", "confidence", "class_id"]
 
 @pytest.fixture(scope="module")
 def eng32(weights_path):
-    e = zly.Engine(weights_path, dtype=zly.DTYPE_FP32, max_batch=4, max_dets=512, warmup_runs=1)
+    e = zly.Engine(weights_path, dtype=zly.DTYPE_FP32, max_batch=4, max_dets=512, warmup_runs=1, flags=zly.FLAG_DUMP_LOGITS)
     yield e
     e.close()
 

@@ -2,8 +2,8 @@
 // stream/graph orchestration.  Compiled with hipcc; the kernels live in kernels_*.hip.
 //
 // Path (reference OnnxInferenceEngine::runInference, src/inference/onnx_engine.cpp:518-646):
-//   preprocess -> YOLOv8 forward (63 convs as 60 MFMA launches, SPPF pools, 2 upsamples, 3 head
-//   decodes) -> decode+threshold -> class-aware NMS -> fixed-size result slab per frame.
+//   preprocess -> YOLOv8 forward (57 convs as 54 MFMA launches, SPPF pools, 2 upsamples) -> fused Detect
+//   tail (6 final 1x1 convs + DFL + sigmoid + decode/threshold) -> class-aware NMS -> result slab per frame.
 //
 // HBM layout: every activation is NHWC, batch-major, in the engine dtype (bf16 or fp32).  Concat
 // and C2f's split never move data: producers write into channel slices of the consumer's concat
@@ -59,6 +59,7 @@ struct Op {
     // sppf / upsample / head
     int c = 0;                         // sppf: hidden width; upsample: channels
     int level = 0, stride_px = 0, anchor_off = 0;
+    HeadArgs head{};                   // OP_HEAD: fused Detect tail
     double flops = 0, bytes = 0;
 };
 
@@ -79,6 +80,7 @@ struct zly_engine {
     std::vector<Op> ops;
     int in_buf = -1;
     std::map<std::string, std::pair<int, int>> tap_index;   // conv name -> (op index, tap slot)
+    std::map<std::string, std::pair<int, int>> tap_final;   // final Detect convs -> (logits buffer, channel offset)
 
     void* d_weights = nullptr;
     float* d_head = nullptr;          // [max_batch][4+nc][N]
@@ -173,6 +175,18 @@ struct PlanBuilder {
                    (double)op.cout * r0->cin * op.ks * op.ks * e->esz + (res.buf >= 0 ? (double)Ho * Wo * op.cout * e->esz : 0.0);
         e->ops.push_back(op);
         for (size_t i = 0; i < names.size(); ++i) e->tap_index[names[i]] = std::make_pair((int)e->ops.size() - 1, (int)i);
+        return true;
+    }
+    // repack + upload the weights of a conv that is executed inside another kernel (fused Detect tail)
+    bool pack_only(const std::string& name, int cin_store, size_t* w_off, size_t* b_off, int* nk) {
+        const ConvRec* r = e->model.find(name);
+        if (!r || r->k != 1) { err = "conv missing from model file: " + name; return false; }
+        std::vector<uint8_t> w;
+        std::vector<float> b;
+        int cout = 0, cout_pad = 0;
+        repack_conv({r}, cin_store, kstep, e->dtype == ZLY_DTYPE_BF16, &w, &b, &cout, &cout_pad, nk);
+        *w_off = append(w.data(), w.size());
+        *b_off = append(b.data(), b.size() * sizeof(float));
         return true;
     }
     // C2f(c1 -> c2, n bottlenecks): cv1 writes [0,2c) of the concat buffer, bottleneck i reads
@@ -272,6 +286,13 @@ static int build_plan(zly_engine* e, std::string* err)
     const int ncp = (m.nc + 3) / 4 * 4;
     int anchor_off = 0;
     e->N = fh[0] * fw[0] + fh[1] * fw[1] + fh[2] * fw[2];
+    if (m.nc > 80) { *err = "nc > 80 is not supported by the fused Detect kernel"; return ZLY_ERR_MODEL_LOAD; }
+    Op hd;
+    hd.kind = OP_HEAD; hd.name = "detect.tail(1x1 convs+DFL+sigmoid+decode)";
+    if (hd.name.size() > 47) hd.name.resize(47);
+    struct PendingLevel { size_t wb, bb, wc, bc; int hb2, hc2, hout; };
+    PendingLevel pend[3];
+    int block0 = 0;
     for (int l = 0; l < 3 && ok; ++l) {
         const std::string L = std::to_string(l);
         const int hd1 = pb.add_buffer("detect." + L + ".stem", fh[l], fw[l], c2 + c3);
@@ -281,19 +302,25 @@ static int build_plan(zly_engine* e, std::string* err)
         ok = ok && pb.conv({"model.22.cv2." + L + ".0", "model.22.cv3." + L + ".0"}, View{feats[l], 0, fch[l]}, View{hd1, 0, c2 + c3});
         ok = ok && pb.conv({"model.22.cv2." + L + ".1"}, View{hd1, 0, c2}, View{hb2, 0, c2});
         ok = ok && pb.conv({"model.22.cv3." + L + ".1"}, View{hd1, c2, c3}, View{hc2, 0, c3});
-        ok = ok && pb.conv({"model.22.cv2." + L + ".2"}, View{hb2, 0, c2}, View{hout, 0, 64}, View{-1, 0, 0}, true);
-        ok = ok && pb.conv({"model.22.cv3." + L + ".2"}, View{hc2, 0, c3}, View{hout, 64, m.nc}, View{-1, 0, 0}, true);
-        if (ok) {
-            Op h; h.kind = OP_HEAD; h.name = "detect." + L + ".decode"; h.in = View{hout, 0, 64 + ncp};
-            h.level = l; h.stride_px = 8 << l; h.anchor_off = anchor_off;
-            h.bytes = (double)fh[l] * fw[l] * ((64 + m.nc) * 4.0 + (4 + m.nc) * 4.0);
-            e->ops.push_back(h);
-        }
+        HeadLevel& hl = hd.head.lv[l];
+        ok = ok && pb.pack_only("model.22.cv2." + L + ".2", c2, &pend[l].wb, &pend[l].bb, &hl.nkb);
+        ok = ok && pb.pack_only("model.22.cv3." + L + ".2", c3, &pend[l].wc, &pend[l].bc, &hl.nkc);
+        pend[l].hb2 = hb2; pend[l].hc2 = hc2; pend[l].hout = hout;
+        hl.box_cs = c2; hl.cls_cs = c3; hl.box_cin = c2; hl.cls_cin = c3;
+        hl.H = fh[l]; hl.W = fw[l]; hl.hw = fh[l] * fw[l]; hl.stride_px = 8 << l; hl.anchor_off = anchor_off; hl.block0 = block0;
+        hl.logits_cs = 64 + ncp;
+        block0 += (hl.hw + 63) / 64;
+        const double macs = (double)hl.hw * (c2 * 64.0 + (double)c3 * m.nc);
+        hd.flops += 2.0 * macs;
+        hd.bytes += (double)hl.hw * ((c2 + c3) * (double)e->esz + (4 + m.nc) * 4.0) + (c2 * 64.0 + (double)c3 * m.nc) * e->esz;
+        e->tap_final[std::string("model.22.cv2.") + L + ".2"] = std::make_pair(hout, 0);
+        e->tap_final[std::string("model.22.cv3.") + L + ".2"] = std::make_pair(hout, 64);
         e->lvl_h[l] = fh[l]; e->lvl_w[l] = fw[l];
         anchor_off += fh[l] * fw[l];
     }
+    hd.head.nc = m.nc; hd.head.N_total = e->N; hd.head.total_blocks = block0;
+    if (ok) e->ops.push_back(hd);
     if (!ok) { *err = pb.err; return ZLY_ERR_MODEL_LOAD; }
-    Op d; d.kind = OP_DECODE; d.name = "decode+threshold"; d.bytes = (double)(4 + m.nc) * e->N * 4; e->ops.push_back(d);
     Op nm; nm.kind = OP_NMS; nm.name = "nms"; e->ops.push_back(nm);
 
     // device allocations
@@ -305,6 +332,17 @@ static int build_plan(zly_engine* e, std::string* err)
     }
     if (hipMalloc(&e->d_weights, pb.blob.size()) != hipSuccess) { *err = "hipMalloc failed for weights"; return ZLY_ERR_SYSTEM; }
     if (hipMemcpy(e->d_weights, pb.blob.data(), pb.blob.size(), hipMemcpyHostToDevice) != hipSuccess) { *err = "weight upload failed"; return ZLY_ERR_SYSTEM; }
+    for (Op& op : e->ops) {
+        if (op.kind != OP_HEAD) continue;
+        for (int l = 0; l < 3; ++l) {
+            HeadLevel& hl = op.head.lv[l];
+            hl.box_in = e->bufs[(size_t)pend[l].hb2].ptr;
+            hl.cls_in = e->bufs[(size_t)pend[l].hc2].ptr;
+            hl.wb = (const char*)e->d_weights + pend[l].wb; hl.bb = (const float*)((const char*)e->d_weights + pend[l].bb);
+            hl.wc = (const char*)e->d_weights + pend[l].wc; hl.bc = (const float*)((const char*)e->d_weights + pend[l].bc);
+            hl.logits = (e->cfg.flags & ZLY_FLAG_DUMP_LOGITS) ? (float*)e->bufs[(size_t)pend[l].hout].ptr : nullptr;
+        }
+    }
     return ZLY_OK;
 }
 
@@ -344,13 +382,9 @@ static hipError_t run_op(zly_engine* e, const Op& op, int n, const uint8_t* d_sr
         return launch_upsample2x(e->dtype, ib.ptr, ib.C, op.in.co, ob.ptr, ob.C, op.out.co, op.c, n, ib.H, ib.W, s);
     }
     case OP_HEAD: {
-        const Buffer& b = e->bufs[(size_t)op.in.buf];
-        return launch_head((const float*)b.ptr, b.C, e->nc, n, b.H, b.W, op.stride_px, e->d_head, e->N, op.anchor_off, s);
-    }
-    case OP_DECODE: {
-        hipError_t r = hipMemsetAsync(e->d_count, 0, sizeof(int) * (size_t)n, s);
-        if (r != hipSuccess) return r;
-        return launch_decode(e->d_head, e->nc, e->N, n, e->d_desc, e->cfg.conf_thr, e->d_cand, e->d_count, s);
+        HeadArgs h = op.head;
+        h.head = e->d_head; h.desc = e->d_desc; h.conf_thr = e->cfg.conf_thr; h.cand = e->d_cand; h.cand_count = e->d_count;
+        return launch_head_fused(e->dtype, h, n, s);
     }
     case OP_NMS:
         return launch_nms(e->d_cand, e->d_count, e->N, n, e->cfg.iou_thr, e->nc, e->d_scratch,
@@ -743,7 +777,7 @@ int32_t zly_postprocess(zly_engine* e, const float* head, int32_t num_classes, i
     if (r == hipSuccess) r = hipMemsetAsync(d + off_cnt, 0, sizeof(int), e->stream);
     if (r == hipSuccess) r = launch_decode((const float*)d, num_classes, num_boxes, 1, (const FrameDesc*)(d + off_desc), conf_thr,
                                            (Cand*)(d + off_cand), (int*)(d + off_cnt), e->stream);
-    if (r == hipSuccess) r = launch_nms((const Cand*)(d + off_cand), (const int*)(d + off_cnt), num_boxes, 1, iou_thr, num_classes,
+    if (r == hipSuccess) r = launch_nms((const Cand*)(d + off_cand), (int*)(d + off_cnt), num_boxes, 1, iou_thr, num_classes,
                                         (Cand*)(d + off_scr), d + off_slab, cap, 0, e->stream);
     if (r == hipSuccess) r = hipMemcpyAsync(hslab.data(), d + off_slab, slab, hipMemcpyDeviceToHost, e->stream);
     if (r == hipSuccess) r = hipStreamSynchronize(e->stream);
@@ -769,10 +803,18 @@ int32_t zly_debug_tap(zly_engine* e, const char* name, int32_t idx, float* out, 
     if (std::string(name) == "images") { buf = e->in_buf; co = 0; C = 3; }
     else {
         auto it = e->tap_index.find(name);
-        if (it == e->tap_index.end()) return fail(ZLY_ERR_INVALID_ARGUMENT, std::string("unknown tap: ") + name);
-        const Op& op = e->ops[(size_t)it->second.first];
-        buf = op.out.buf; co = op.out.co + op.tap_co[(size_t)it->second.second]; C = op.tap_c[(size_t)it->second.second];
-        f32 = op.out_f32 != 0;
+        auto jt = e->tap_final.find(name);
+        if (it != e->tap_index.end()) {
+            const Op& op = e->ops[(size_t)it->second.first];
+            buf = op.out.buf; co = op.out.co + op.tap_co[(size_t)it->second.second]; C = op.tap_c[(size_t)it->second.second];
+            f32 = op.out_f32 != 0;
+        } else if (jt != e->tap_final.end()) {
+            if (!(e->cfg.flags & ZLY_FLAG_DUMP_LOGITS))
+                return fail(ZLY_ERR_INVALID_ARGUMENT, std::string("tap ") + name + " is computed inside the fused Detect kernel; create the engine with ZLY_FLAG_DUMP_LOGITS");
+            buf = jt->second.first; co = jt->second.second; C = co == 0 ? 64 : e->nc; f32 = true;
+        } else {
+            return fail(ZLY_ERR_INVALID_ARGUMENT, std::string("unknown tap: ") + name);
+        }
     }
     const Buffer& b = e->bufs[(size_t)buf];
     const size_t elems = (size_t)C * b.H * b.W;
@@ -841,7 +883,7 @@ int32_t zly_profile_ops(zly_engine* e, int32_t n, const void* d_frames, int32_t 
         ms_out[i] = (float)(acc[i] / reps);
         const int k = e->ops[i].kind;
         if (k == OP_PREPROCESS) e->stats.total_preprocess_ms += acc[i];
-        else if (k == OP_DECODE || k == OP_NMS) e->stats.total_postprocess_ms += acc[i];
+        else if (k == OP_NMS) e->stats.total_postprocess_ms += acc[i];
         else e->stats.total_forward_ms += acc[i];
     }
     e->last_n = n;

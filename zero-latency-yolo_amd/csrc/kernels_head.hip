@@ -1,0 +1,206 @@
+// kernels_head.hip -- the whole YOLOv8 Detect tail in ONE launch for all three pyramid levels:
+//   final 1x1 convs of the box branch (c2 -> 4*16 DFL logits) and class branch (c3 -> nc logits) as
+//   two small MFMA GEMMs per 16-anchor tile, then, straight from the fp32 accumulators,
+//   DFL softmax-expectation, dist2bbox (xywh) * stride, class sigmoid  -> rows of the [4+nc][N] fp32
+//   head tensor (the "output0" tensor of the reference, onnx_engine.cpp:50,767-796), and the
+//   reference's decode + confidence threshold (onnx_engine.cpp:779-816) with wavefront-ballot
+//   compaction into the per-frame candidate list that the NMS kernel consumes.
+// It replaces 6 conv launches + 3 head launches + a memset + the decode launch, and the fp32 logit
+// round trip through HBM.  decode here and decode_kernel (kernels_post.hip, used by zly_postprocess)
+// apply the same comparisons to the same fp32 values, so both give the same candidates.
+#include "zly_internal.h"
+
+#pragma clang fp contract(off)
+
+namespace zly {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+template <typename T> struct HFrag;
+template <> struct HFrag<bf16_t> { typedef bf16x8 type; static constexpr int EPL = 8; static constexpr int KSTEP = 32; };
+template <> struct HFrag<float>  { typedef f32x4  type; static constexpr int EPL = 4; static constexpr int KSTEP = 16; };
+
+__device__ __forceinline__ f32x4 hmma(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 hmma(f32x4 a, f32x4 b, f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], c, 0, 0, 0);
+    return c;
+}
+
+// One wave = 16 anchors (MFMA columns).  Lane (p = lane & 15, kq = lane >> 4) ends up holding, for
+// every 16-channel tile c, channels c*16 + kq*4 + {0..3} of anchor p.
+template <typename T, int CTC>
+__global__ __launch_bounds__(256) void head_fused_kernel(const HeadArgs a)
+{
+    typedef typename HFrag<T>::type F;
+    constexpr int EPL = HFrag<T>::EPL, KSTEP = HFrag<T>::KSTEP, WTILE = 16 * KSTEP;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int p = lane & 15, kq = lane >> 4;
+    const int f = blockIdx.y;
+    const int bx = blockIdx.x;
+    const int li = bx >= a.lv[2].block0 ? 2 : (bx >= a.lv[1].block0 ? 1 : 0);
+    const HeadLevel& L = a.lv[li];
+    const int anchor0 = (bx - L.block0) * 64 + wave * 16;
+    if (anchor0 >= L.hw) return;                           // wave-uniform; no barriers in this kernel
+    const int an = anchor0 + p;
+    const bool valid = an < L.hw;
+    const size_t pix = (size_t)f * L.hw + (valid ? an : 0);
+
+    F zero;
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) zero[j] = (T)0.0f;
+
+    // ---- box branch: [64 x cin] . [cin x 16] ----------------------------------------------------
+    f32x4 accb[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) accb[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    {
+        const T* x = static_cast<const T*>(L.box_in) + pix * L.box_cs;
+        const T* w = static_cast<const T*>(L.wb) + lane * EPL;
+        for (int s = 0; s < L.nkb; ++s) {
+            const int ci = s * KSTEP + kq * EPL;
+            const F af = (valid && ci < L.box_cin) ? *reinterpret_cast<const F*>(x + ci) : zero;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const F wf = *reinterpret_cast<const F*>(w + ((size_t)c * L.nkb + s) * WTILE);
+                accb[c] = hmma(wf, af, accb[c]);
+            }
+        }
+    }
+    // ---- class branch: [nc x cin] . [cin x 16] ---------------------------------------------------
+    f32x4 accc[CTC];
+#pragma unroll
+    for (int c = 0; c < CTC; ++c) accc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    {
+        const T* x = static_cast<const T*>(L.cls_in) + pix * L.cls_cs;
+        const T* w = static_cast<const T*>(L.wc) + lane * EPL;
+        for (int s = 0; s < L.nkc; ++s) {
+            const int ci = s * KSTEP + kq * EPL;
+            const F af = (valid && ci < L.cls_cin) ? *reinterpret_cast<const F*>(x + ci) : zero;
+#pragma unroll
+            for (int c = 0; c < CTC; ++c) {
+                const F wf = *reinterpret_cast<const F*>(w + ((size_t)c * L.nkc + s) * WTILE);
+                accc[c] = hmma(wf, af, accc[c]);
+            }
+        }
+    }
+
+    // ---- DFL: side c (l,t,r,b) = channel tile c; its 16 bins live in the 4 lanes {p, p+16, p+32, p+48} ----
+    float dist[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(L.bb + c * 16 + kq * 4);
+        const f32x4 v = accb[c] + bias;
+        accb[c] = v;
+        float m = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+        m = fmaxf(m, __shfl_xor(m, 16));
+        m = fmaxf(m, __shfl_xor(m, 32));
+        float se = 0.f, sw = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float e = expf(v[r] - m);
+            se += e;
+            sw += e * (float)(kq * 4 + r);
+        }
+        se += __shfl_xor(se, 16); sw += __shfl_xor(sw, 16);
+        se += __shfl_xor(se, 32); sw += __shfl_xor(sw, 32);
+        dist[c] = sw / se;
+    }
+    const float ax = (float)(an % L.W) + 0.5f, ay = (float)(an / L.W) + 0.5f;
+    const float x1 = ax - dist[0], y1 = ay - dist[1], x2 = ax + dist[2], y2 = ay + dist[3];
+    const float sp = (float)L.stride_px;
+    const float cx = (x1 + x2) / 2.0f * sp, cy = (y1 + y2) / 2.0f * sp, bw = (x2 - x1) * sp, bh = (y2 - y1) * sp;
+
+    // ---- class scores + running arg-max in the reference's order (strict >, lowest class wins ties) ----
+    float best = 0.0f;
+    int cls = -1;
+    f32x4 score[CTC];
+#pragma unroll
+    for (int c = 0; c < CTC; ++c) {
+        const int ch = c * 16 + kq * 4;
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(L.bc + ch);
+        const f32x4 z = accc[c] + bias;
+        accc[c] = z;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float sc = 1.0f / (1.0f + expf(-z[r]));
+            score[c][r] = sc;
+            if (ch + r < a.nc && sc > best) { best = sc; cls = ch + r; }
+        }
+    }
+#pragma unroll
+    for (int d = 16; d <= 32; d <<= 1) {
+        const float ob = __shfl_xor(best, d);
+        const int oc = __shfl_xor(cls, d);
+        if (ob > best || (ob == best && oc >= 0 && (cls < 0 || oc < cls))) { best = ob; cls = oc; }
+    }
+
+    // ---- outputs ------------------------------------------------------------------------------------
+    if (a.head && valid) {
+        float* h = a.head + (size_t)f * (4 + a.nc) * a.N_total + L.anchor_off + an;
+        const float bv = kq == 0 ? cx : (kq == 1 ? cy : (kq == 2 ? bw : bh));
+        h[(size_t)kq * a.N_total] = bv;
+#pragma unroll
+        for (int c = 0; c < CTC; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ch = c * 16 + kq * 4 + r;
+                if (ch < a.nc) h[(size_t)(4 + ch) * a.N_total] = score[c][r];
+            }
+    }
+    if (L.logits && valid) {
+        float* lg = L.logits + pix * L.logits_cs;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) *reinterpret_cast<f32x4*>(lg + c * 16 + kq * 4) = accb[c];
+#pragma unroll
+        for (int c = 0; c < CTC; ++c)
+            if (c * 16 + kq * 4 < L.logits_cs - 64) *reinterpret_cast<f32x4*>(lg + 64 + c * 16 + kq * 4) = accc[c];
+    }
+    if (a.cand) {
+        // decode + threshold (onnx_engine.cpp:799-816); lanes 0..15 stand for the wave's 16 anchors
+        const bool pass = valid && kq == 0 && best >= a.conf_thr && cls >= 0;
+        const unsigned long long mask = __ballot(pass);
+        if (mask != 0ull) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&a.cand_count[f], __popcll(mask));
+            base = __shfl(base, 0);
+            if (pass) {
+                const int slot = base + __popcll(mask & ((1ull << lane) - 1ull));
+                if (slot < a.N_total) {
+                    const FrameDesc d = a.desc[f];
+                    Cand c;
+                    c.x = cx / (float)d.w; c.y = cy / (float)d.h; c.w = bw / (float)d.w; c.h = bh / (float)d.h;
+                    c.conf = best; c.cls = cls; c.anchor = L.anchor_off + an; c.pad_ = 0;
+                    a.cand[(size_t)f * a.N_total + slot] = c;
+                }
+            }
+        }
+    }
+}
+
+typedef void (*head_fn)(const HeadArgs);
+template <typename T> static head_fn pick_head(int ctc) {
+    switch (ctc) {
+        case 1: return head_fused_kernel<T, 1>;
+        case 2: return head_fused_kernel<T, 2>;
+        case 3: return head_fused_kernel<T, 3>;
+        case 4: return head_fused_kernel<T, 4>;
+        case 5: return head_fused_kernel<T, 5>;
+    }
+    return nullptr;
+}
+
+hipError_t launch_head_fused(int dtype, const HeadArgs& a, int n, hipStream_t s)
+{
+    const int ctc = (a.nc + 15) / 16;
+    head_fn fn = dtype == ZLY_DTYPE_BF16 ? pick_head<bf16_t>(ctc) : pick_head<float>(ctc);
+    if (!fn) return hipErrorInvalidValue;                  // nc > 80 is not supported by this kernel
+    hipLaunchKernelGGL(fn, dim3(a.total_blocks, n), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace zly

@@ -1,5 +1,5 @@
 // kernels_misc.hip -- the non-GEMM stages of the detect path on gfx950: preprocess, SPPF max-pools,
-// nearest-2x upsample, Detect-head decode (DFL + dist2bbox + sigmoid).  All HBM/LDS-bound byte and
+// nearest-2x upsample (the Detect head lives in kernels_head.hip).  All HBM/LDS-bound byte and
 // element work: coalesced 16-byte accesses, no MFMA.
 #include "zly_internal.h"
 
@@ -178,77 +178,6 @@ hipError_t launch_upsample2x(int dtype, const void* in, int in_cs, int in_co, vo
         hipLaunchKernelGGL((upsample2x_kernel<float, 4>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
                            (const float*)in, in_cs, in_co, (float*)out, out_cs, out_co, C, H, W, total);
     }
-    return hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------------------
-// Detect head decode for one pyramid level: DFL softmax-expectation over 16 bins per box side,
-// dist2bbox (xywh, anchor offset 0.5) * stride, class sigmoid -> rows of the [4+nc][N] fp32 head
-// tensor, i.e. the "output0" tensor the reference's postProcess indexes (onnx_engine.cpp:767-796).
-// logits: fp32 [n][H*W][64+nc] (box-branch logits then class logits, written by the two final 1x1
-// convs).  One workgroup = 64 anchors: logits staged through LDS so that both the global reads
-// (anchor-major) and the global writes (row-major over anchors) are coalesced.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ logits, int cs, int nc, int H, int W,
-                                                   float stride_px, float* __restrict__ head, int N_total, int anchor_off)
-{
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int ldw = cs + 1;                          // odd row pitch: conflict-free column reads
-    float* L = lds;                                  // [64][ldw]
-    float* dist = lds + 64 * ldw;                    // [4][64]
-    const int f = blockIdx.y;
-    const int hw = H * W;
-    const int a0 = blockIdx.x * 64;
-    const int na = min(64, hw - a0);
-    const float* src = logits + ((size_t)f * hw + a0) * cs;
-    for (int i = threadIdx.x; i < na * cs; i += 256) {
-        const int a = i / cs, c = i - a * cs;
-        L[a * ldw + c] = src[i];
-    }
-    __syncthreads();
-    const int a = threadIdx.x & 63, q = threadIdx.x >> 6;
-    if (a < na) {                                    // DFL for side q (0=l, 1=t, 2=r, 3=b)
-        const float* x = L + a * ldw + q * 16;
-        float mx = x[0];
-#pragma unroll
-        for (int j = 1; j < 16; ++j) mx = fmaxf(mx, x[j]);
-        float se = 0.f, sw = 0.f;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const float e = expf(x[j] - mx);
-            se += e;
-            sw += e * (float)j;
-        }
-        dist[q * 64 + a] = sw / se;
-    }
-    __syncthreads();
-    float* out = head + (size_t)f * (4 + nc) * N_total + anchor_off + a0;
-    if (a < na) {
-        const int ai = a0 + a;
-        const float ax = (float)(ai % W) + 0.5f, ay = (float)(ai / W) + 0.5f;
-        const float l = dist[a], t = dist[64 + a], r = dist[128 + a], b = dist[192 + a];
-        const float x1 = ax - l, y1 = ay - t, x2 = ax + r, y2 = ay + b;
-        float v;
-        if (q == 0) v = (x1 + x2) / 2.0f;
-        else if (q == 1) v = (y1 + y2) / 2.0f;
-        else if (q == 2) v = x2 - x1;
-        else v = y2 - y1;
-        out[(size_t)q * N_total + a] = v * stride_px;
-        for (int c = q; c < nc; c += 4) {
-            const float z = L[a * ldw + 64 + c];
-            out[(size_t)(4 + c) * N_total + a] = 1.0f / (1.0f + expf(-z));
-        }
-    }
-}
-
-hipError_t launch_head(const float* logits, int cs, int nc, int n, int H, int W, int stride_px,
-                       float* head, int N_total, int anchor_off, hipStream_t s)
-{
-    const size_t lds = ((size_t)64 * (cs + 1) + 256) * sizeof(float);
-    if (lds > 160 * 1024) return hipErrorInvalidValue;
-    if (lds > 64 * 1024) hipFuncSetAttribute((const void*)head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    dim3 grid((H * W + 63) / 64, n);
-    hipLaunchKernelGGL(head_kernel, grid, dim3(256), lds, s, logits, cs, nc, H, W, (float)stride_px, head, N_total, anchor_off);
     return hipGetLastError();
 }
 

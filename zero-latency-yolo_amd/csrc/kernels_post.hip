@@ -44,6 +44,7 @@ __global__ __launch_bounds__(256) void decode_kernel(const float* __restrict__ h
     base = __shfl(base, 0);
     if (pass) {
         const int slot = base + __popcll(mask & ((1ull << lane) - 1ull));
+        if (slot >= N) return;
         const FrameDesc d = desc[f];
         Cand c;
         c.x = h[i] / (float)d.w;
@@ -104,7 +105,7 @@ __device__ __forceinline__ bool cand_before(const Cand& a, const Cand& b)
 #define NMS_THREADS 1024
 #define NMS_MAX_CLASSES 1024
 
-__global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const Cand* __restrict__ cand_all, const int* __restrict__ cand_count,
+__global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const Cand* __restrict__ cand_all, int* __restrict__ cand_count,
                                                           int N, float iou_thr, int nc, Cand* __restrict__ scratch_all,
                                                           unsigned char* __restrict__ slabs, int cap, uint32_t tag0)
 {
@@ -119,6 +120,8 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const Cand* __restrict
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int n = cand_count[f];
     if (n > N) n = N;
+    __syncthreads();
+    if (tid == 0) cand_count[f] = 0;       // self-cleaning: the next frame's decode appends from 0 again (no memset launch)
     const bool in_lds = n <= NMS_LDS_CAP;
     const Cand* gsrc = cand_all + (size_t)f * N;
     const Cand* src = gsrc;
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const Cand* __restrict
     }
 }
 
-hipError_t launch_nms(const Cand* cand, const int* cand_count, int N, int n, float iou_thr, int nc,
+hipError_t launch_nms(const Cand* cand, int* cand_count, int N, int n, float iou_thr, int nc,
                       Cand* scratch, void* slabs, int cap, uint32_t tag0, hipStream_t s)
 {
     if (nc > NMS_MAX_CLASSES) return hipErrorInvalidValue;

@@ -50,15 +50,32 @@ hipError_t launch_nchw_to_nhwc8(int dtype, const float* in_nchw, void* out_nhwc8
 hipError_t launch_sppf_pool(int dtype, void* buf, int cs, int c, int n, int H, int W, hipStream_t s);
 hipError_t launch_upsample2x(int dtype, const void* in, int in_cs, int in_co, void* out, int out_cs, int out_co,
                              int C, int n, int H, int W, hipStream_t s);
-hipError_t launch_head(const float* logits, int cs, int nc, int n, int H, int W, int stride_px,
-                       float* head, int N_total, int anchor_off, hipStream_t s);
 hipError_t launch_tap_to_nchw(int dtype, const void* in, int cs, int co, int C, int H, int W, int idx, float* out, hipStream_t s);
+
+// kernels_head.hip -- fused Detect head (final 1x1 convs + DFL + dist2bbox + sigmoid + decode/threshold)
+struct HeadLevel {
+    const void* box_in; const void* cls_in;   // [n][H*W][cs] activations of the two branches' second 3x3 convs
+    int box_cs, cls_cs, box_cin, cls_cin;
+    const void* wb; const void* wc;           // final 1x1 weights, tiled in MFMA lane order
+    const float* bb; const float* bc;         // biases (padded to 16)
+    int nkb, nkc;                             // k-steps of the two GEMMs
+    int H, W, hw, stride_px, anchor_off, block0;
+    float* logits; int logits_cs;             // optional fp32 [n][H*W][logits_cs] dump (debug taps), or null
+};
+struct HeadArgs {
+    HeadLevel lv[3];
+    int nc, N_total, total_blocks;
+    float* head;                              // [n][4+nc][N_total] or null
+    const FrameDesc* desc; float conf_thr;
+    struct Cand* cand; int* cand_count;
+};
+hipError_t launch_head_fused(int dtype, const HeadArgs& a, int n, hipStream_t s);
 
 // kernels_post.hip
 struct Cand { float x, y, w, h; float conf; int cls; int anchor; int pad_; };   // 32 bytes
 hipError_t launch_decode(const float* head, int nc, int N, int n, const FrameDesc* desc, float conf_thr,
                          Cand* cand, int* cand_count, hipStream_t s);
-hipError_t launch_nms(const Cand* cand, const int* cand_count, int N, int n, float iou_thr, int nc,
+hipError_t launch_nms(const Cand* cand, int* cand_count, int N, int n, float iou_thr, int nc,
                       Cand* scratch, void* slabs, int cap, uint32_t tag0, hipStream_t s);
 
 }  // namespace zly

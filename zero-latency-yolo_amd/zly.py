@@ -25,6 +25,7 @@ ERR_INVALID_INPUT = 203
 ERR_SYSTEM = 300
 DTYPE_FP32, DTYPE_BF16 = 0, 1
 SLAB_OVERFLOW = 1
+FLAG_DUMP_LOGITS = 1
 
 # every symbol include/zly.h declares (tests/test_abi.py checks the library exports them all)
 SYMBOLS = [
@@ -44,7 +45,7 @@ class Config(C.Structure):
     _fields_ = [("weights_path", C.c_char_p), ("model_w", C.c_int32), ("model_h", C.c_int32),
                 ("conf_thr", C.c_float), ("iou_thr", C.c_float), ("max_batch", C.c_int32),
                 ("max_dets", C.c_int32), ("device", C.c_int32), ("dtype", C.c_int32),
-                ("warmup_runs", C.c_int32), ("use_graph", C.c_int32)]
+                ("warmup_runs", C.c_int32), ("use_graph", C.c_int32), ("flags", C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -116,7 +117,7 @@ class Engine:
 
     def __init__(self, weights: Optional[str] = None, model_w: int = 416, model_h: int = 416, conf_thr: float = 0.5,
                  iou_thr: float = 0.45, max_batch: int = 1, max_dets: int = 64, device: int = 0,
-                 dtype: int = DTYPE_BF16, warmup_runs: int = 1, use_graph: bool = True):
+                 dtype: int = DTYPE_BF16, warmup_runs: int = 1, use_graph: bool = True, flags: int = 0):
         self.lib = load_library()
         cfg = Config()
         self.lib.zly_default_config(C.byref(cfg))
@@ -126,6 +127,7 @@ class Engine:
         cfg.conf_thr, cfg.iou_thr = conf_thr, iou_thr
         cfg.max_batch, cfg.max_dets, cfg.device, cfg.dtype = max_batch, max_dets, device, dtype
         cfg.warmup_runs, cfg.use_graph = warmup_runs, 1 if use_graph else 0
+        cfg.flags = flags
         self.cfg = cfg
         h = C.c_void_p()
         _check(self.lib, self.lib.zly_create(C.byref(cfg), C.byref(h)))
