@@ -326,6 +326,7 @@ static int build_plan(zly_engine* e, std::string* err)
     // device allocations
     const int B = e->cfg.max_batch;
     for (Buffer& b : e->bufs) {
+        if (b.elems_per_frame() * (size_t)B >= (1ull << 31)) { *err = "activation buffer " + b.name + " exceeds 2^31 elements: lower max_batch"; return ZLY_ERR_INVALID_ARGUMENT; }
         const size_t bytes = b.elems_per_frame() * (b.f32 ? 4 : e->esz) * (size_t)B;
         if (hipMalloc(&b.ptr, bytes) != hipSuccess) { *err = "hipMalloc failed for " + b.name; return ZLY_ERR_SYSTEM; }
         hipMemset(b.ptr, 0, bytes);

@@ -45,7 +45,9 @@ __device__ __forceinline__ f32x4 mma_step(f32x4 a, f32x4 b, f32x4 c) {
 
 template <typename T> __device__ __forceinline__ float silu(float v);
 template <> __device__ __forceinline__ float silu<float>(float v) { return v / (1.0f + expf(-v)); }
-template <> __device__ __forceinline__ float silu<bf16_t>(float v) { return v * __frcp_rn(1.0f + __expf(-v)); }
+// bf16 path: v_exp_f32 + v_rcp_f32 (1 ulp each), 5 VALU instead of the 16 of an IEEE divide; the result is
+// rounded to bf16 (8 bits) anyway.  The epilogue was the largest VALU consumer of the LDS kernel.
+template <> __device__ __forceinline__ float silu<bf16_t>(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.442695041f)); }
 
 __device__ __forceinline__ void store4(bf16_t* p, f32x4 v) {
     bf16x4 o;
@@ -263,41 +265,42 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(const ConvArgs a, int 
     const bf16_t* __restrict__ in = static_cast<const bf16_t*>(a.in) + a.in_co;
     const bf16_t* __restrict__ wbase = static_cast<const bf16_t*>(a.wgt) + (size_t)(blockIdx.y * CT) * a.nk * 512;
 
-    int tile = blockIdx.x;
-    if (tile >= total_tiles) return;
-    int chunk = 0;
-
-    u32x4 rp[NPU_T], rw[NWU_T];
-    auto stage_load = [&](int tl, int c) {
+    // per-thread staging geometry, computed once: unit i of this thread is pixel (upy, upx) of the patch,
+    // 16-byte piece q; its source offset relative to the patch origin and its weight offset are constants
+    int upy[NPU_T], upx[NPU_T], usrc[NPU_T], uwsrc[NWU_T];
+#pragma unroll
+    for (int i = 0; i < NPU_T; ++i) {
+        const int u = min(tid + i * 256, NPU - 1);
+        const int px = u >> 2, q = u & 3;
+        upy[i] = px / PW; upx[i] = px - upy[i] * PW;
+        usrc[i] = (upy[i] * a.W + upx[i]) * a.in_cs + q * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < NWU_T; ++i) {
+        const int u = min(tid + i * 256, NWU - 1);
+        const int ti = u >> 6, l = u & 63;                     // ti = tap * CT + ct
+        const int t = ti / CT, ct = ti - t * CT;
+        uwsrc[i] = (ct * a.nk + t * nchunks) * 512 + l * 8;
+    }
+    auto stage_load = [&](int tl, int c, u32x4 (&rp)[NPU_T], u32x4 (&rw)[NWU_T]) {
         const int b = tl / tiles_per_img;
         const int r = tl - b * tiles_per_img;
         const int ty = r / tiles_x, tx = r - ty * tiles_x;
         const int iy_base = ty * G::TH * S - 1, ix_base = tx * G::TW * S - 1;
-        const bf16_t* inb = in + (size_t)b * a.H * a.W * a.in_cs + c * 32;
+        // wave-uniform base of the patch origin (may point before the frame: only dereferenced when in range)
+        const bf16_t* inb = in + ((long)b * a.H * a.W + (long)iy_base * a.W + ix_base) * a.in_cs + c * 32;
 #pragma unroll
         for (int i = 0; i < NPU_T; ++i) {
-            const int u = tid + i * 256;
             u32x4 v = {0u, 0u, 0u, 0u};
-            if (u < NPU) {
-                const int px = u >> 2, q = u & 3;
-                const int py = px / PW, pxx = px - py * PW;
-                const int iy = iy_base + py, ix = ix_base + pxx;
-                if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
-                    v = *reinterpret_cast<const u32x4*>(inb + ((size_t)iy * a.W + ix) * a.in_cs + q * 8);
-            }
+            if ((unsigned)(iy_base + upy[i]) < (unsigned)a.H && (unsigned)(ix_base + upx[i]) < (unsigned)a.W)
+                v = *reinterpret_cast<const u32x4*>(inb + usrc[i]);
             rp[i] = v;
         }
+        const bf16_t* wc = wbase + c * 512;
 #pragma unroll
-        for (int i = 0; i < NWU_T; ++i) {
-            const int u = tid + i * 256;
-            if (u < NWU) {
-                const int ti = u >> 6, l = u & 63;             // ti = tap * CT + ct
-                const int t = ti / CT, ct = ti - t * CT;
-                rw[i] = *reinterpret_cast<const u32x4*>(wbase + ((size_t)ct * a.nk + t * nchunks + c) * 512 + l * 8);
-            }
-        }
+        for (int i = 0; i < NWU_T; ++i) rw[i] = *reinterpret_cast<const u32x4*>(wc + uwsrc[i]);
     };
-    auto stage_store = [&]() {
+    auto stage_store = [&](const u32x4 (&rp)[NPU_T], const u32x4 (&rw)[NWU_T]) {
 #pragma unroll
         for (int i = 0; i < NPU_T; ++i) {
             const int u = tid + i * 256;
@@ -316,65 +319,82 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(const ConvArgs a, int 
 #pragma unroll
         for (int t = 0; t < PT; ++t) acc[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    stage_load(tile, 0);
-    while (true) {
-        stage_store();
-        __syncthreads();
-        int ntile = tile, nchunk = chunk + 1;
-        if (nchunk == nchunks) { nchunk = 0; ntile = tile + gridDim.x; }
-        const bool has_next = ntile < total_tiles;
-        if (has_next) stage_load(ntile, nchunk);          // lands in registers while the MFMAs below run
-
+    // 9 taps of one staged chunk; the epilogue runs after a tile's last chunk
+    auto compute = [&](int tl, int c) {
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int ky = t / 3, kx = t - ky * 3;
             bf16x8 wf[CT], af[PT];
 #pragma unroll
-            for (int c = 0; c < CT; ++c)
-                wf[c] = *reinterpret_cast<const bf16x8*>(lw + (t * CT + c) * 1024 + lane * 16);
+            for (int cc = 0; cc < CT; ++cc)
+                wf[cc] = *reinterpret_cast<const bf16x8*>(lw + (t * CT + cc) * 1024 + lane * 16);
 #pragma unroll
             for (int i = 0; i < PT; ++i) {
                 const int row = wave * PT + i;
                 af[i] = *reinterpret_cast<const bf16x8*>(lpatch + ((row * S + ky) * PW + p * S + kx) * PITCH + kq * 16);
             }
 #pragma unroll
-            for (int c = 0; c < CT; ++c)
+            for (int cc = 0; cc < CT; ++cc)
 #pragma unroll
-                for (int i = 0; i < PT; ++i) acc[c][i] = mma_step(wf[c], af[i], acc[c][i]);
+                for (int i = 0; i < PT; ++i) acc[cc][i] = mma_step(wf[cc], af[i], acc[cc][i]);
         }
-
-        if (chunk == nchunks - 1) {
-            // epilogue for `tile`: lane holds channels ch..ch+3 of pixel (oy, ox)
-            const int b = tile / tiles_per_img;
-            const int r = tile - b * tiles_per_img;
-            const int ty = r / tiles_x, tx = r - ty * tiles_x;
-            const int ox = tx * G::TW + p;
+        if (c != nchunks - 1) return;
+        // epilogue for tile tl: lane holds channels ch..ch+3 of pixel (oy, ox)
+        const int b = tl / tiles_per_img;
+        const int r = tl - b * tiles_per_img;
+        const int ty = r / tiles_x, tx = r - ty * tiles_x;
+        const int ox = tx * G::TW + p;
 #pragma unroll
-            for (int c = 0; c < CT; ++c) {
-                const int ch = (blockIdx.y * CT + c) * 16 + kq * 4;
-                const bool chok = ch < a.Cout;
-                const f32x4 bias = chok ? *reinterpret_cast<const f32x4*>(a.bias + ch) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int cc = 0; cc < CT; ++cc) {
+            const int ch = (blockIdx.y * CT + cc) * 16 + kq * 4;
+            const bool chok = ch < a.Cout;
+            const f32x4 bias = chok ? *reinterpret_cast<const f32x4*>(a.bias + ch) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int i = 0; i < PT; ++i) {
-                    const int oy = ty * G::TH + wave * PT + i;
-                    f32x4 v = acc[c][i] + bias;
-                    acc[c][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (!chok || oy >= a.Ho || ox >= a.Wo) continue;
-                    const size_t m = ((size_t)b * a.Ho + oy) * a.Wo + ox;
-                    if (a.act) {
+            for (int i = 0; i < PT; ++i) {
+                const int oy = ty * G::TH + wave * PT + i;
+                f32x4 v = acc[cc][i] + bias;
+                acc[cc][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (!chok || oy >= a.Ho || ox >= a.Wo) continue;
+                const int m = (b * a.Ho + oy) * a.Wo + ox;          // element offsets fit 31 bits (checked by the engine)
+                if (a.act) {
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) v[q] = silu<bf16_t>(v[q]);
-                    }
-                    if (a.res) v += load4(static_cast<const bf16_t*>(a.res) + m * a.res_cs + a.res_co + ch);
-                    if (a.out_f32) store4(static_cast<float*>(a.out) + m * a.out_cs + a.out_co + ch, v);
-                    else           store4(static_cast<bf16_t*>(a.out) + m * a.out_cs + a.out_co + ch, v);
+                    for (int q = 0; q < 4; ++q) v[q] = silu<bf16_t>(v[q]);
                 }
+                if (a.res) v += load4(static_cast<const bf16_t*>(a.res) + (m * a.res_cs + a.res_co + ch));
+                if (a.out_f32) store4(static_cast<float*>(a.out) + (m * a.out_cs + a.out_co + ch), v);
+                else           store4(static_cast<bf16_t*>(a.out) + (m * a.out_cs + a.out_co + ch), v);
             }
         }
-        __syncthreads();                                    // every wave is done reading this chunk's LDS image
-        if (!has_next) break;
-        tile = ntile;
-        chunk = nchunk;
+    };
+
+    // item stream of this workgroup: (tile, chunk) with tile = blockIdx.x + k * gridDim.x; two items are
+    // always in flight in registers (sets A and B) ahead of the one being computed from LDS
+    auto advance = [&](int& tl, int& c) { if (++c == nchunks) { c = 0; tl += gridDim.x; } };
+    int t0 = blockIdx.x, c0 = 0;                 // item being computed
+    if (t0 >= total_tiles) return;
+    int t1 = t0, c1 = c0; advance(t1, c1);       // next item
+    int t2 = t1, c2 = c1; advance(t2, c2);       // the one after
+    u32x4 rpA[NPU_T], rwA[NWU_T], rpB[NPU_T], rwB[NWU_T];
+    stage_load(t0, c0, rpA, rwA);
+    if (t1 < total_tiles) stage_load(t1, c1, rpB, rwB);
+    while (true) {
+        // ---- item (t0,c0) from set A ----
+        stage_store(rpA, rwA);
+        __syncthreads();
+        if (t2 < total_tiles) stage_load(t2, c2, rpA, rwA);
+        compute(t0, c0);
+        __syncthreads();
+        if (t1 >= total_tiles) break;
+        // ---- item (t1,c1) from set B ----
+        int t3 = t2, c3 = c2; advance(t3, c3);
+        stage_store(rpB, rwB);
+        __syncthreads();
+        if (t3 < total_tiles) stage_load(t3, c3, rpB, rwB);
+        compute(t1, c1);
+        __syncthreads();
+        if (t2 >= total_tiles) break;
+        t0 = t2; c0 = c2; t1 = t3; c1 = c3;
+        t2 = t1; c2 = c1; advance(t2, c2);
     }
 }
 
@@ -522,9 +542,9 @@ hipError_t launch_conv(int dtype, const ConvArgs& a, const ConvLaunch& cfg, hipS
         const int n = a.M / (a.Ho * a.Wo);
         const int tiles_per_img = tiles_x * tiles_y, total = tiles_per_img * n;
         int gx = total;
-        const int max_wgs = 2 * 256;                       // two resident workgroups per CU
-        if (gx * ytiles > max_wgs) gx = (max_wgs + ytiles - 1) / ytiles;
-        if (gx > total) gx = total;
+        const int max_wgs = 2 * 256;                       // two resident workgroups per CU (LDS / VGPR budget)
+        if (gx * ytiles > max_wgs) gx = max_wgs / ytiles;  // never more than are resident: a persistent workgroup
+        if (gx > total) gx = total;                        // that has to wait for a slot runs a whole round alone
         hipLaunchKernelGGL(fn, dim3(gx, ytiles, 1), dim3(256), lds_bytes(a.stride, cfg.pt, cfg.ct), s, a, tiles_x, tiles_per_img, total);
         return hipGetLastError();
     }
