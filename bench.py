@@ -6,10 +6,11 @@ YOLOv8n 416x416, batch 1 / 64, 1-8 MI355X).
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the hot path (preprocess -> YOLOv8n forward -> decode -> NMS -> result slab)
-over one batch of synthetic frames that are already resident in HBM.  The headline `value` is the
-BASELINE config[1] workload (batch 1, bf16, latency path); the batch-64 throughput path (config[2])
-and the host-to-host p50 detect latency are measured in the same run and reported in the same JSON
-line.  With N > 1 each rank (one process per GPU) detects its own frames -- frames are sharded
+over one batch of synthetic frames that are already resident in HBM.  BASELINE.json's metric is
+"frames/sec + p50 detect latency, YOLOv8n 416x416 batch 1/64": the headline `value` is frames/s on the
+batch-64 throughput configuration (configs[2]); the batch-1 latency configuration (configs[1]: frames/s
+with resident frames, and the host-to-host p50 detect latency through zly_detect) is measured in the
+same run and reported in the same JSON line as `latency_path_b1`.  With N > 1 each rank (one process per GPU) detects its own frames -- frames are sharded
 one-per-GPU, no data-path collective -- and the per-frame result slabs are all-gathered over
 RCCL/xGMI, overlapped with the next step (weak scaling: per-GPU work is fixed).
 
@@ -134,9 +135,9 @@ def cpu_baseline(frames_np, seconds=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)
-    ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--batch", type=int, default=1, help="frames per step per GPU for the headline value (BASELINE config[1] = 1)")
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=64, help="frames per step per GPU for the headline value (BASELINE configs[2] = 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the batch-64 / latency / roofline legs")
     ap.add_argument("--eager", action="store_true", help="no hipGraph replay")
@@ -166,7 +167,7 @@ def main():
     frames_np = zm.synth_frames(n_sets * big, 416, 416, seed=20250328 + rank, rects=False)
     d_all = torch.from_numpy(frames_np).cuda()
     sets_b = [d_all[i * B:(i + 1) * B] for i in range(n_sets * big // B)][:64]
-    sets_big = [d_all[i * big:(i + 1) * big] for i in range(n_sets)]
+    sets_1 = [d_all[i:i + 1] for i in range(64)]
     sb = eng.slab_bytes
 
     def slab_bufs(n):
@@ -184,19 +185,19 @@ def main():
         "metric": "frames_per_sec", "value": round(value, 1), "unit": "frames/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 5),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"YOLOv8-nano 416x416 batch={B} bf16 per MI355X, frames resident in HBM, "
+        "config": {"workload": f"YOLOv8-nano 416x416 batch={B} streaming throughput path, bf16, per MI355X, frames resident in HBM, "
                                f"preprocess+forward+decode+NMS per step" + (", slabs all-gathered over RCCL" if world > 1 else ""),
                    "frames_per_step_per_gpu": B, "global_frames_per_step": world * B, "conf": 0.5, "iou": 0.45,
                    "weights": "seeded synthetic (no real weights offline)", "graph": not a.eager,
                    "parallelism": f"frame-sharded x{world}" if world > 1 else "single GPU"},
     }
     if not a.no_extras:
-        # ---- BASELINE config[2]: batch 64 streaming throughput ----------------------------------------
-        k64 = max(20, a.steps // 10)
-        log(f"headline {value:.0f} frames/s; batch-64 leg")
-        dt64 = timed(eng, sets_big, big, k64, max(5, a.warmup // 10), slab_bufs(big), sp, world, gather_bufs(big))
-        result["throughput_b64"] = {"value": round(world * big * k64 / dt64, 1), "unit": "frames/s", "steps": k64,
-                                    "ms_per_step": round(dt64 / k64 * 1e3, 4), "frames_per_step_per_gpu": big}
+        # ---- BASELINE configs[1]: batch 1, the latency path, frames resident in HBM ---------------------
+        k1 = max(200, a.steps * 2)
+        log(f"headline {value:.0f} frames/s; batch-1 leg")
+        dt1 = timed(eng, sets_1, 1, k1, max(20, a.warmup), slab_bufs(1), sp, world, gather_bufs(1))
+        result["latency_path_b1"] = {"value": round(world * k1 / dt1, 1), "unit": "frames/s", "steps": k1,
+                                     "ms_per_step": round(dt1 / k1 * 1e3, 5), "frames_per_step_per_gpu": 1}
         if rank == 0:
             # ---- p50 detect latency, request bytes in host memory -> detections in host memory -----------
             log("latency leg")
@@ -209,14 +210,15 @@ def main():
                 eng.detect(f_host[i % 16])
                 lat.append(time.perf_counter() - t0)
             lat = np.array(lat) * 1e3
-            result["latency_host_to_host"] = {"p50_ms": round(float(np.percentile(lat, 50)), 4), "p90_ms": round(float(np.percentile(lat, 90)), 4),
-                                              "p99_ms": round(float(np.percentile(lat, 99)), 4), "samples": len(lat),
-                                              "note": "zly_detect: 519 KB H2D over PCIe + path + slab D2H, synchronous"}
-            # ---- roofline of the dominant kernel family (the 60 MFMA conv launches of one forward) -------
+            result["latency_path_b1"].update({"p50_detect_ms_host_to_host": round(float(np.percentile(lat, 50)), 4),
+                                              "p90_detect_ms_host_to_host": round(float(np.percentile(lat, 90)), 4),
+                                              "p99_detect_ms_host_to_host": round(float(np.percentile(lat, 99)), 4), "samples": len(lat),
+                                              "note": "zly_detect: 519 KB H2D over PCIe + path + slab D2H, synchronous"})
+            # ---- roofline of the dominant kernel family (the MFMA conv launches of one forward) ----------
             log("roofline leg (per-op hipEvent profile)")
             ops = eng.ops()
             roof = {}
-            for nb, frames in ((B, sets_b[0]), (big, sets_big[0])):
+            for nb, frames in ((B, sets_b[0]), (1, sets_1[0])):
                 ms = eng.profile_ops(frames.data_ptr(), nb, 416, 416, reps=20)
                 conv = [(o, m) for o, m in zip(ops, ms) if o["kind"] == 1]
                 conv_ms = float(sum(m for _, m in conv))
@@ -225,7 +227,7 @@ def main():
                 tfl = flops / (conv_ms * 1e-3) / 1e12
                 gbs = bytes_ / (conv_ms * 1e-3) / 1e9
                 top = sorted(conv, key=lambda t: -t[1])[:3]
-                roof[nb] = {"bound": "mfma", "kernel": "conv_igemm_kernel (all conv launches of one forward)",
+                roof[nb] = {"bound": "mfma", "kernel": "conv_igemm_kernel + conv3x3_lds_kernel (all MFMA conv launches of one forward)",
                             "launches_per_step": len(conv), "achieved": round(tfl, 3), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                             "frac": round(tfl / PEAK_BF16_TFLOPS, 5), "traffic": None,
                             "algorithmic_gflop_per_step": round(flops / 1e9, 3), "kernel_ms_per_step": round(conv_ms, 4),
@@ -234,7 +236,8 @@ def main():
                                          "peak_GBps": PEAK_HBM_GBS, "frac": round(gbs / PEAK_HBM_GBS, 4)},
                             "all_ops_ms_per_step": round(float(ms.sum()), 4),
                             "other_ops_ms": {o["name"]: round(float(m), 4) for o, m in zip(ops, ms) if o["kind"] != 1},
-                            "slowest_convs_ms": {o["name"]: round(float(m), 4) for o, m in top}}
+                            "slowest_convs_ms": {o["name"]: round(float(m), 4) for o, m in top},
+                            "method": "mean of 20 eager passes with a hipEvent pair around every launch on the engine's stream (zly_profile_ops)"}
                 if a.dump_ops:
                     with open(a.dump_ops, "a") as f:
                         f.write(f"# batch {nb}: per-op mean ms over 20 eager reps (hipEvents around every launch)\n")
@@ -244,7 +247,12 @@ def main():
                             f.write(f"{o['name']:44s} {o['kind']:4d} {m:9.4f} {gf:9.3f} {mb:9.2f} {gf / max(m, 1e-9):9.2f} {mb / max(m, 1e-9):9.1f}\n")
                         f.write(f"{'TOTAL':44s} {'':4s} {float(ms.sum()):9.4f}\n\n")
             result["roofline"] = roof[B]
-            result["roofline_b64"] = roof[big]
+            if B != 1:
+                result["roofline_b1"] = roof[1]
+            hdrs = [h for h, _ in eng.read_slabs(min(B, 64))]
+            result["candidates_per_frame_last_profiled_batch"] = {"median": float(np.median([int(h["n_candidates"]) for h in hdrs])),
+                                                                  "max": int(max(int(h["n_candidates"]) for h in hdrs)),
+                                                                  "kept_max": int(max(int(h["n_kept"]) for h in hdrs))}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(frames_np[:8])
         result["speedup_vs_cpu_baseline"] = round(value / result["cpu_baseline"]["value"], 1)

@@ -59,6 +59,7 @@ struct Op {
     // sppf / upsample / head
     int c = 0;                         // sppf: hidden width; upsample: channels
     int level = 0, stride_px = 0, anchor_off = 0;
+    int lane = 0;                      // 0 = main stream; 1, 2 = Detect-branch streams that run beside the neck
     HeadArgs head{};                   // OP_HEAD: fused Detect tail
     double flops = 0, bytes = 0;
 };
@@ -99,6 +100,8 @@ struct zly_engine {
     size_t scratch_f32_elems = 0;
 
     hipStream_t stream = nullptr;
+    hipStream_t side[2] = {nullptr, nullptr};     // P3 / P4 Detect branches (forked from and joined to the main stream)
+    hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join[2] = {nullptr, nullptr};
     std::map<int, hipGraphExec_t> graphs;   // batch size -> captured forward+decode
     int last_n = 0;
 
@@ -323,6 +326,34 @@ static int build_plan(zly_engine* e, std::string* err)
     if (!ok) { *err = pb.err; return ZLY_ERR_MODEL_LOAD; }
     Op nm; nm.kind = OP_NMS; nm.name = "nms"; e->ops.push_back(nm);
 
+    // The Detect branches of P3 and P4 only depend on model.15 / model.18: issue them right behind their
+    // producer on side streams (lanes 1, 2) so that, inside the captured graph, they run BESIDE the rest of
+    // the neck (model.16-21) instead of after it.  These launches are latency/issue-bound and leave most of
+    // the chip idle, so the overlap is nearly free.  The tail op joins all lanes.
+    {
+        std::vector<Op> main_ops, lane_ops[3];
+        for (Op& op : e->ops) {
+            int lane = 0;
+            if (op.kind == OP_CONV && op.name.rfind("model.22.cv", 0) == 0) {
+                const int lvl = op.name[13] - '0';                 // "model.22.cvX.L...": L is character 13
+                lane = lvl == 0 ? 1 : (lvl == 1 ? 2 : 0);
+            }
+            op.lane = lane;
+            (lane == 0 ? main_ops : lane_ops[lane]).push_back(op);
+        }
+        std::vector<Op> ordered;
+        for (Op& op : main_ops) {
+            ordered.push_back(op);
+            if (op.kind == OP_CONV && op.name == "model.15.cv2") for (Op& x : lane_ops[1]) ordered.push_back(x);
+            if (op.kind == OP_CONV && op.name == "model.18.cv2") for (Op& x : lane_ops[2]) ordered.push_back(x);
+        }
+        if (ordered.size() != e->ops.size()) { *err = "internal: op reordering lost ops"; return ZLY_ERR_MODEL_LOAD; }
+        e->ops.swap(ordered);
+        e->tap_index.clear();
+        for (size_t i = 0; i < e->ops.size(); ++i)
+            for (size_t k = 0; k < e->ops[i].taps.size(); ++k) e->tap_index[e->ops[i].taps[k]] = std::make_pair((int)i, (int)k);
+    }
+
     // device allocations
     const int B = e->cfg.max_batch;
     for (Buffer& b : e->bufs) {
@@ -394,14 +425,39 @@ static hipError_t run_op(zly_engine* e, const Op& op, int n, const uint8_t* d_sr
     return hipErrorInvalidValue;
 }
 
-// ops [first, last) -- the graph-capturable middle of the path is [1, ops.size()-1)
+// ops [first, last) -- the graph-capturable middle of the path is [1, ops.size()-1).  Side-lane ops are
+// launched on the engine's side streams behind a fork event; the Detect tail (OP_HEAD) joins them.
 static hipError_t run_ops(zly_engine* e, size_t first, size_t last, int n, const uint8_t* d_src, void* d_slabs_out, uint32_t tag0, hipStream_t s)
 {
-    for (size_t i = first; i < last; ++i) {
-        hipError_t r = run_op(e, e->ops[i], n, d_src, d_slabs_out, tag0, s);
-        if (r != hipSuccess) return r;
+    bool forked[3] = {false, false, false};
+    hipError_t r = hipSuccess;
+    auto join_all = [&]() {
+        for (int l = 1; l <= 2 && r == hipSuccess; ++l) {
+            if (!forked[l]) continue;
+            r = hipEventRecord(e->ev_join[l - 1], e->side[l - 1]);
+            if (r == hipSuccess) r = hipStreamWaitEvent(s, e->ev_join[l - 1], 0);
+            forked[l] = false;
+        }
+    };
+    for (size_t i = first; i < last && r == hipSuccess; ++i) {
+        const Op& op = e->ops[i];
+        hipStream_t st = s;
+        // measured: at batch 1 the cross-stream edges cost more than the overlap buys (0.27 -> 0.34 ms/frame);
+        // from batch 16 up the Detect branches are long enough to pay (1.42 -> 1.38 ms per 64 frames)
+        if (op.lane > 0 && n >= 16) {
+            st = e->side[op.lane - 1];
+            if (!forked[op.lane]) {
+                r = hipEventRecord(e->ev_fork[op.lane - 1], s);
+                if (r == hipSuccess) r = hipStreamWaitEvent(st, e->ev_fork[op.lane - 1], 0);
+                forked[op.lane] = true;
+                if (r != hipSuccess) break;
+            }
+        }
+        if (op.kind == OP_HEAD || op.kind == OP_NMS) { join_all(); if (r != hipSuccess) break; }
+        r = run_op(e, op, n, d_src, d_slabs_out, tag0, st);
     }
-    return hipSuccess;
+    if (r == hipSuccess) join_all();
+    return r;
 }
 
 static int run_path(zly_engine* e, int n, const uint8_t* d_src, void* d_slabs_out, uint32_t tag0, hipStream_t s, bool with_pre)
@@ -486,6 +542,7 @@ static void destroy_engine(zly_engine* e)
     if (!e) return;
     hipSetDevice(e->dev);
     if (e->stream) hipStreamSynchronize(e->stream);
+    for (int i = 0; i < 2; ++i) if (e->side[i]) hipStreamSynchronize(e->side[i]);
     for (auto& kv : e->graphs) hipGraphExecDestroy(kv.second);
     for (Buffer& b : e->bufs) if (b.ptr) hipFree(b.ptr);
     void* dptrs[] = {e->d_weights, e->d_head, e->d_cand, e->d_scratch, e->d_count, e->d_slabs, e->d_desc, e->d_stage, e->d_scratch_f32};
@@ -493,6 +550,11 @@ static void destroy_engine(zly_engine* e)
     if (e->h_desc) hipHostFree(e->h_desc);
     if (e->h_stage) hipHostFree(e->h_stage);
     if (e->h_slabs) hipHostFree(e->h_slabs);
+    for (int i = 0; i < 2; ++i) {
+        if (e->ev_fork[i]) hipEventDestroy(e->ev_fork[i]);
+        if (e->ev_join[i]) hipEventDestroy(e->ev_join[i]);
+        if (e->side[i]) hipStreamDestroy(e->side[i]);
+    }
     if (e->stream) hipStreamDestroy(e->stream);
     delete e;
 }
@@ -543,7 +605,13 @@ int32_t zly_create(const zly_config* cfg, zly_engine** out)
     int rc = load_zlyw(e->weights_path.c_str(), &e->model, &err);
     if (rc != ZLY_OK) { destroy_engine(e); return fail(rc, err); }
     e->nc = e->model.nc;
-    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { destroy_engine(e); return fail(ZLY_ERR_SYSTEM, "hipStreamCreate failed"); }
+    bool sok = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; i < 2 && sok; ++i) {
+        sok = hipStreamCreateWithFlags(&e->side[i], hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreateWithFlags(&e->ev_fork[i], hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming) == hipSuccess;
+    }
+    if (!sok) { destroy_engine(e); return fail(ZLY_ERR_SYSTEM, "hipStreamCreate failed"); }
     rc = build_plan(e, &err);
     if (rc != ZLY_OK) { destroy_engine(e); return fail(rc, err); }
 
