@@ -92,74 +92,58 @@ __device__ __forceinline__ bool cand_before(const Cand& a, const Cand& b)
 }
 
 // ------------------------------------------------------------------------------------------------
-// NMS: one workgroup (16 waves) per frame.
-//   1. rank sort by (class asc, confidence desc, anchor asc): rank = #candidates ordered before.
-//   2. classes are independent (:866), so each class segment of the sorted list is handed to ONE
-//      wave, which runs the reference's greedy loop: for kept i, lanes test j = i+1.. in parallel
-//      and set removed[j] when IoU > thr (strict, :871).
-//   3. kept flags are compacted in sorted order with ballot prefix sums and written to the slab.
-// n <= NMS_LDS_CAP candidates are handled in LDS; beyond that the same code runs on a global
-// scratch area (the reference has no cap on candidates, so neither does this kernel).
+// NMS: one workgroup (8 waves) per frame.  Classes are independent (:866), so the frame is split by class:
+//   1. histogram of candidates per class (LDS atomics) + exclusive scan -> class segments; candidates are
+//      scattered into their segment (arrival order inside a segment is irrelevant, see 2).
+//   2. one WAVE per class segment of <= 64 candidates, entirely in registers: lane j holds candidate j;
+//      its rank inside the class under (confidence desc, anchor asc) -- the reference's sort key
+//      (:846-851) with the anchor index breaking exact ties -- is counted with 64 shuffles; the sorted
+//      order is materialised through the segment's LDS slots; then the reference's greedy loop (:856-875):
+//      for every still-alive i in order, all lanes j > i evaluate IoU(i, j) at once and one __ballot
+//      clears the suppressed ones (strict >, :871).
+//   3. kept counts per class -> exclusive scan -> every wave writes its survivors at their final position:
+//      output order = class asc, confidence desc, exactly the reference's.
+// Frames with more than NMS_LDS_CAP candidates, or a class with more than 64, take the general path
+// below (same results, LDS/global flags instead of registers).
 // ------------------------------------------------------------------------------------------------
 #define NMS_LDS_CAP 1024
-#define NMS_THREADS 1024
+#define NMS_THREADS 512
+#define NMS_WAVES (NMS_THREADS / 64)
 #define NMS_MAX_CLASSES 1024
 
-__global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const Cand* __restrict__ cand_all, int* __restrict__ cand_count,
-                                                          int N, float iou_thr, int nc, Cand* __restrict__ scratch_all,
-                                                          unsigned char* __restrict__ slabs, int cap, uint32_t tag0)
+__device__ __forceinline__ void write_det(zly_det* dst, const Cand& c)
 {
-    __shared__ Cand lds_src[NMS_LDS_CAP];
-    __shared__ Cand lds_sorted[NMS_LDS_CAP];
-    __shared__ int seg_start[NMS_MAX_CLASSES];
-    __shared__ int seg_end[NMS_MAX_CLASSES];
-    __shared__ int wave_tot[NMS_THREADS / 64];
-    __shared__ int run_base;
+    zly_det d;
+    d.x = c.x; d.y = c.y; d.w = c.w; d.h = c.h;
+    d.confidence = c.conf; d.class_id = c.cls;
+    d.track_id = 0; d.pad_ = 0; d.timestamp = 0;          // track_id = 0 (:812); timestamp is set by the host
+    *dst = d;
+}
 
-    const int f = blockIdx.x;
+// general path: rank sort over the whole frame + per-class greedy loop with removed flags in memory
+__device__ void nms_general(const Cand* gsrc, int n, float iou_thr, int nc, Cand* sorted, bool in_lds,
+                            int* seg_start, int* seg_end, int* wave_tot, int* run_base, zly_det* dets, int cap, int* n_kept_out)
+{
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int n = cand_count[f];
-    if (n > N) n = N;
-    __syncthreads();
-    if (tid == 0) cand_count[f] = 0;       // self-cleaning: the next frame's decode appends from 0 again (no memset launch)
-    const bool in_lds = n <= NMS_LDS_CAP;
-    const Cand* gsrc = cand_all + (size_t)f * N;
-    const Cand* src = gsrc;
-    Cand* sorted = in_lds ? lds_sorted : scratch_all + (size_t)f * N;
-
-    const size_t slab_bytes = sizeof(zly_slab_header) + (size_t)cap * sizeof(zly_det);
-    zly_slab_header* hdr = reinterpret_cast<zly_slab_header*>(slabs + (size_t)f * slab_bytes);
-    zly_det* dets = reinterpret_cast<zly_det*>(hdr + 1);
-
     for (int c = tid; c < nc; c += NMS_THREADS) { seg_start[c] = -1; seg_end[c] = -1; }
-    if (in_lds) {
-        for (int i = tid; i < n; i += NMS_THREADS) lds_src[i] = gsrc[i];
-        src = lds_src;
-    }
-    if (tid == 0) run_base = 0;
+    if (tid == 0) *run_base = 0;
     __syncthreads();
-
-    // 1. rank sort (the removed flag lives in pad_, cleared by decode)
     for (int i = tid; i < n; i += NMS_THREADS) {
-        const Cand ci = src[i];
+        const Cand ci = gsrc[i];
         int rank = 0;
-        for (int j = 0; j < n; ++j) rank += cand_before(src[j], ci) ? 1 : 0;
+        for (int j = 0; j < n; ++j) rank += cand_before(gsrc[j], ci) ? 1 : 0;
         sorted[rank] = ci;
     }
     if (!in_lds) __threadfence();
     __syncthreads();
-
-    // class segment boundaries
     for (int i = tid; i < n; i += NMS_THREADS) {
         const int c = sorted[i].cls;
         if (i == 0 || sorted[i - 1].cls != c) seg_start[c] = i;
         if (i == n - 1 || sorted[i + 1].cls != c) seg_end[c] = i + 1;
     }
     __syncthreads();
-
-    // 2. greedy suppression, one wave per class segment
     if (n > 1) {
-        for (int c = wave; c < nc; c += NMS_THREADS / 64) {
+        for (int c = wave; c < nc; c += NMS_WAVES) {
             const int s = seg_start[c], e = seg_end[c];
             if (s < 0 || e - s < 2) continue;
             for (int i = s; i < e - 1; ++i) {
@@ -177,39 +161,171 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const Cand* __restrict
     }
     if (!in_lds) __threadfence();
     __syncthreads();
-
-    // 3. ordered compaction of the survivors
     for (int i0 = 0; i0 < n; i0 += NMS_THREADS) {
         const int i = i0 + tid;
         const bool keep = (i < n) && (sorted[i].pad_ == 0);
         const unsigned long long mask = __ballot(keep);
         if (lane == 0) wave_tot[wave] = __popcll(mask);
         __syncthreads();
-        int off = run_base;
+        int off = *run_base;
         for (int w = 0; w < wave; ++w) off += wave_tot[w];
         if (keep) {
             const int o = off + __popcll(mask & ((1ull << lane) - 1ull));
-            if (o < cap) {
-                const Cand c = sorted[i];
-                zly_det d;
-                d.x = c.x; d.y = c.y; d.w = c.w; d.h = c.h;
-                d.confidence = c.conf; d.class_id = c.cls;
-                d.track_id = 0; d.pad_ = 0; d.timestamp = 0;     // track_id = 0 (:812); timestamp set by the host
-                dets[o] = d;
-            }
+            if (o < cap) write_det(&dets[o], sorted[i]);
         }
         __syncthreads();
         if (tid == 0) {
             int t = 0;
-            for (int w = 0; w < NMS_THREADS / 64; ++w) t += wave_tot[w];
-            run_base += t;
+            for (int w = 0; w < NMS_WAVES; ++w) t += wave_tot[w];
+            *run_base += t;
         }
         __syncthreads();
     }
+    if (tid == 0) *n_kept_out = *run_base;
+}
+
+__global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const Cand* __restrict__ cand_all, int* __restrict__ cand_count,
+                                                          int N, float iou_thr, int nc, Cand* __restrict__ scratch_all,
+                                                          unsigned char* __restrict__ slabs, int cap, uint32_t tag0)
+{
+    __shared__ Cand lds_c[NMS_LDS_CAP];           // class-bucketed candidates (general path: sorted list)
+    __shared__ int cls_cnt[NMS_MAX_CLASSES];      // candidates per class -> later: kept per class
+    __shared__ int cls_off[NMS_MAX_CLASSES];      // segment start per class
+    __shared__ int cls_fill[NMS_MAX_CLASSES];     // scatter cursor / general path seg_end
+    __shared__ int wave_tot[NMS_WAVES];
+    __shared__ int sh_misc[4];                    // [0] max class count, [1] run_base, [2] n_kept
+
+    const int f = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int n = cand_count[f];
+    if (n > N) n = N;
+    const Cand* gsrc = cand_all + (size_t)f * N;
+    const size_t slab_bytes = sizeof(zly_slab_header) + (size_t)cap * sizeof(zly_det);
+    zly_slab_header* hdr = reinterpret_cast<zly_slab_header*>(slabs + (size_t)f * slab_bytes);
+    zly_det* dets = reinterpret_cast<zly_det*>(hdr + 1);
+
+    for (int c = tid; c < nc; c += NMS_THREADS) { cls_cnt[c] = 0; cls_fill[c] = 0; }
+    if (tid == 0) { sh_misc[0] = 0; sh_misc[2] = 0; }
+    __syncthreads();
+    if (tid == 0) cand_count[f] = 0;       // self-cleaning: the next frame's decode appends from 0 again (no memset launch)
+
+    bool fast = n <= NMS_LDS_CAP;
+    Cand mine[(NMS_LDS_CAP + NMS_THREADS - 1) / NMS_THREADS];
+    if (fast) {
+        // 1. histogram
+#pragma unroll
+        for (int k = 0; k < (NMS_LDS_CAP + NMS_THREADS - 1) / NMS_THREADS; ++k) {
+            const int i = tid + k * NMS_THREADS;
+            if (i < n) { mine[k] = gsrc[i]; atomicAdd(&cls_cnt[mine[k].cls], 1); }
+        }
+        __syncthreads();
+        // exclusive scan over classes by wave 0 (nc <= 1024: 16 per lane), and the largest class
+        if (wave == 0) {
+            int run = 0, mx = 0;
+            for (int c0 = 0; c0 < nc; c0 += 64) {
+                const int c = c0 + lane;
+                const int v = c < nc ? cls_cnt[c] : 0;
+                int incl = v;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+                if (c < nc) cls_off[c] = run + incl - v;
+                run += __shfl(incl, 63);
+                mx = max(mx, v);
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) mx = max(mx, __shfl_xor(mx, d));
+            if (lane == 0) sh_misc[0] = mx;
+        }
+        __syncthreads();
+        fast = sh_misc[0] <= 64;
+    }
+    if (!fast) {
+        // general path (uniform per workgroup)
+        const bool in_lds = n <= NMS_LDS_CAP;
+        __syncthreads();
+        nms_general(gsrc, n, iou_thr, nc, in_lds ? lds_c : scratch_all + (size_t)f * N, in_lds,
+                    cls_off, cls_fill, wave_tot, &sh_misc[1], dets, cap, &sh_misc[2]);
+        __syncthreads();
+        if (tid == 0) {
+            hdr->n_kept = sh_misc[2]; hdr->n_candidates = n;
+            hdr->flags = sh_misc[2] > cap ? ZLY_SLAB_OVERFLOW : 0u; hdr->frame_tag = tag0 + (uint32_t)f;
+        }
+        return;
+    }
+
+    // scatter into class segments
+#pragma unroll
+    for (int k = 0; k < (NMS_LDS_CAP + NMS_THREADS - 1) / NMS_THREADS; ++k) {
+        const int i = tid + k * NMS_THREADS;
+        if (i < n) {
+            const int c = mine[k].cls;
+            lds_c[cls_off[c] + atomicAdd(&cls_fill[c], 1)] = mine[k];
+        }
+    }
+    __syncthreads();
+
+    // 2. one wave per class segment
+    for (int c = wave; c < nc; c += NMS_WAVES) {
+        const int L = cls_cnt[c];
+        if (L == 0) continue;
+        const int s = cls_off[c];
+        Cand me;
+        if (lane < L) me = lds_c[s + lane];
+        else { me.x = me.y = me.w = me.h = 0.f; me.conf = -1.f; me.cls = c; me.anchor = 0x7fffffff; me.pad_ = 0; }
+        // rank inside the class: (confidence desc, anchor asc)
+        int rank = 0;
+        for (int k = 0; k < L; ++k) {
+            const float oc = __shfl(me.conf, k);
+            const int oa = __shfl(me.anchor, k);
+            rank += (oc > me.conf || (oc == me.conf && oa < me.anchor)) ? 1 : 0;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane < L) lds_c[s + rank] = me;                  // every lane read its candidate before any lane writes
+        __builtin_amdgcn_wave_barrier();
+        if (lane < L) me = lds_c[s + lane];                  // lane j now holds the j-th candidate of the sorted class
+        unsigned long long alive = L >= 64 ? ~0ull : ((1ull << L) - 1ull);
+        for (int i = 0; i < L - 1; ++i) {
+            if (!((alive >> i) & 1ull)) continue;            // wave-uniform
+            Cand bi;
+            bi.x = __shfl(me.x, i); bi.y = __shfl(me.y, i); bi.w = __shfl(me.w, i); bi.h = __shfl(me.h, i);
+            const bool kill = lane > i && lane < L && iou_cxcywh(bi, me) > iou_thr;
+            alive &= ~__ballot(kill);
+        }
+        // park the result: survivors first (sorted order), count in cls_cnt
+        const bool keep = lane < L && ((alive >> lane) & 1ull);
+        const int kpos = __popcll(alive & ((1ull << lane) - 1ull));
+        __builtin_amdgcn_wave_barrier();
+        if (keep) lds_c[s + kpos] = me;
+        if (lane == 0) cls_cnt[c] = __popcll(alive);
+    }
+    __syncthreads();
+
+    // 3. exclusive scan of kept counts, then write survivors at their final positions
+    if (wave == 0) {
+        int run = 0;
+        for (int c0 = 0; c0 < nc; c0 += 64) {
+            const int c = c0 + lane;
+            const int v = c < nc ? cls_cnt[c] : 0;
+            int incl = v;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+            if (c < nc) cls_fill[c] = run + incl - v;        // output offset of class c
+            run += __shfl(incl, 63);
+        }
+        if (lane == 0) sh_misc[2] = run;
+    }
+    __syncthreads();
+    for (int c = wave; c < nc; c += NMS_WAVES) {
+        const int K = cls_cnt[c];
+        if (lane < K) {
+            const int o = cls_fill[c] + lane;
+            if (o < cap) write_det(&dets[o], lds_c[cls_off[c] + lane]);
+        }
+    }
     if (tid == 0) {
-        hdr->n_kept = run_base;
+        hdr->n_kept = sh_misc[2];
         hdr->n_candidates = n;
-        hdr->flags = run_base > cap ? ZLY_SLAB_OVERFLOW : 0u;
+        hdr->flags = sh_misc[2] > cap ? ZLY_SLAB_OVERFLOW : 0u;
         hdr->frame_tag = tag0 + (uint32_t)f;
     }
 }
