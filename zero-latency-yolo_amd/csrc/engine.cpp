@@ -99,6 +99,8 @@ struct zly_engine {
     float* d_scratch_f32 = nullptr;   // stage-level entry points
     size_t scratch_f32_elems = 0;
 
+    bool stem_fused = false;          // bf16 + 16-channel stem: preprocess and model.0 are one kernel on the detect paths
+    StemArgs stem{};
     hipStream_t stream = nullptr;
     hipStream_t side[2] = {nullptr, nullptr};     // P3 / P4 Detect branches (forked from and joined to the main stream)
     hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join[2] = {nullptr, nullptr};
@@ -183,7 +185,7 @@ struct PlanBuilder {
     // repack + upload the weights of a conv that is executed inside another kernel (fused Detect tail)
     bool pack_only(const std::string& name, int cin_store, size_t* w_off, size_t* b_off, int* nk) {
         const ConvRec* r = e->model.find(name);
-        if (!r || r->k != 1) { err = "conv missing from model file: " + name; return false; }
+        if (!r) { err = "conv missing from model file: " + name; return false; }
         std::vector<uint8_t> w;
         std::vector<float> b;
         int cout = 0, cout_pad = 0;
@@ -246,6 +248,10 @@ static int build_plan(zly_engine* e, std::string* err)
 
     bool ok = true;
     ok = ok && pb.conv({"model.0"}, View{e->in_buf, 0, 8}, View{a0, 0, ch[0]});
+    size_t stem_w = 0, stem_b = 0;
+    int stem_nk = 0;
+    e->stem_fused = e->dtype == ZLY_DTYPE_BF16 && ch[0] == 16;
+    if (e->stem_fused) ok = ok && pb.pack_only("model.0", 4, &stem_w, &stem_b, &stem_nk) && stem_nk == 2;
     ok = ok && pb.conv({"model.1"}, View{a0, 0, ch[0]}, View{a1, 0, ch[1]});
     ok = ok && pb.c2f("model.2", View{a1, 0, ch[1]}, View{a2, 0, ch[1]}, nb[0], true, H4, W4);
     ok = ok && pb.conv({"model.3"}, View{a2, 0, ch[1]}, View{a3, 0, ch[2]});
@@ -364,6 +370,12 @@ static int build_plan(zly_engine* e, std::string* err)
     }
     if (hipMalloc(&e->d_weights, pb.blob.size()) != hipSuccess) { *err = "hipMalloc failed for weights"; return ZLY_ERR_SYSTEM; }
     if (hipMemcpy(e->d_weights, pb.blob.data(), pb.blob.size(), hipMemcpyHostToDevice) != hipSuccess) { *err = "weight upload failed"; return ZLY_ERR_SYSTEM; }
+    if (e->stem_fused) {
+        StemArgs& st = e->stem;
+        st.wgt = (const char*)e->d_weights + stem_w; st.bias = (const float*)((const char*)e->d_weights + stem_b);
+        st.out = e->bufs[(size_t)a0].ptr; st.out_cs = ch[0]; st.out_co = 0;
+        st.tw = W; st.th = H; st.Ho = H2; st.Wo = W2; st.Cout = ch[0]; st.tiles_x = stem_tiles_x(W2);
+    }
     for (Op& op : e->ops) {
         if (op.kind != OP_HEAD) continue;
         for (int l = 0; l < 3; ++l) {
@@ -463,25 +475,37 @@ static hipError_t run_ops(zly_engine* e, size_t first, size_t last, int n, const
 static int run_path(zly_engine* e, int n, const uint8_t* d_src, void* d_slabs_out, uint32_t tag0, hipStream_t s, bool with_pre)
 {
     const size_t nops = e->ops.size();
-    if (with_pre) HIP_TRY(run_op(e, e->ops[0], n, d_src, nullptr, 0, s), ZLY_ERR_INFERENCE);
+    // ops[0] = preprocess, ops[1] = model.0.  On the detect paths of the bf16 engine both are ONE kernel
+    // (kernels_stem.hip); zly_forward (caller-supplied fp32 images) keeps the generic model.0 conv.
+    const bool fused = with_pre && e->stem_fused;
+    size_t first = 1;
+    if (fused) {
+        StemArgs st = e->stem;
+        st.src = d_src; st.desc = e->d_desc;
+        HIP_TRY(launch_stem_fused(st, n, s), ZLY_ERR_INFERENCE);
+        first = 2;
+    } else if (with_pre) {
+        HIP_TRY(run_op(e, e->ops[0], n, d_src, nullptr, 0, s), ZLY_ERR_INFERENCE);
+    }
     if (e->cfg.use_graph) {
-        auto it = e->graphs.find(n);
+        const int key = n * 2 + (fused ? 1 : 0);
+        auto it = e->graphs.find(key);
         if (it == e->graphs.end()) {
             // capture on the engine's own stream, then replay on whichever stream the caller uses
             hipGraph_t g = nullptr;
             hipGraphExec_t ge = nullptr;
             HIP_TRY(hipStreamSynchronize(s), ZLY_ERR_INFERENCE);
             HIP_TRY(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal), ZLY_ERR_INFERENCE);
-            hipError_t r = run_ops(e, 1, nops - 1, n, nullptr, nullptr, 0, e->stream);
+            hipError_t r = run_ops(e, first, nops - 1, n, nullptr, nullptr, 0, e->stream);
             hipError_t r2 = hipStreamEndCapture(e->stream, &g);
             if (r != hipSuccess || r2 != hipSuccess) return fail(ZLY_ERR_INFERENCE, std::string("graph capture failed: ") + hipGetErrorString(r != hipSuccess ? r : r2));
             HIP_TRY(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0), ZLY_ERR_INFERENCE);
             hipGraphDestroy(g);
-            it = e->graphs.emplace(n, ge).first;
+            it = e->graphs.emplace(key, ge).first;
         }
         HIP_TRY(hipGraphLaunch(it->second, s), ZLY_ERR_INFERENCE);
     } else {
-        HIP_TRY(run_ops(e, 1, nops - 1, n, nullptr, nullptr, 0, s), ZLY_ERR_INFERENCE);
+        HIP_TRY(run_ops(e, first, nops - 1, n, nullptr, nullptr, 0, s), ZLY_ERR_INFERENCE);
     }
     HIP_TRY(run_op(e, e->ops[nops - 1], n, nullptr, d_slabs_out, tag0, s), ZLY_ERR_INFERENCE);
     e->last_n = n;
@@ -934,7 +958,16 @@ int32_t zly_profile_ops(zly_engine* e, int32_t n, const void* d_frames, int32_t 
     for (int r = 0; r < reps && rcode == ZLY_OK; ++r) {
         hipEventRecord(ev[0], e->stream);
         for (size_t i = 0; i < nops; ++i) {
-            hipError_t hr = run_op(e, e->ops[i], n, (const uint8_t*)d_frames, nullptr, 0, e->stream);
+            hipError_t hr = hipSuccess;
+            if (e->stem_fused && i == 0) {
+                // shipped path: preprocess is part of the stem kernel; its time is booked on ops[1] (model.0)
+            } else if (e->stem_fused && i == 1) {
+                StemArgs st = e->stem;
+                st.src = (const uint8_t*)d_frames; st.desc = e->d_desc;
+                hr = launch_stem_fused(st, n, e->stream);
+            } else {
+                hr = run_op(e, e->ops[i], n, (const uint8_t*)d_frames, nullptr, 0, e->stream);
+            }
             if (hr != hipSuccess) { rcode = fail(ZLY_ERR_INFERENCE, std::string("profile: ") + hipGetErrorString(hr)); break; }
             hipEventRecord(ev[i + 1], e->stream);
         }

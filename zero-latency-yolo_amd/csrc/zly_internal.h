@@ -52,6 +52,16 @@ hipError_t launch_upsample2x(int dtype, const void* in, int in_cs, int in_co, vo
                              int C, int n, int H, int W, hipStream_t s);
 hipError_t launch_tap_to_nchw(int dtype, const void* in, int cs, int co, int C, int H, int W, int idx, float* out, hipStream_t s);
 
+// kernels_stem.hip -- preprocess fused into the stem conv (bf16, 16-channel stem)
+struct StemArgs {
+    const uint8_t* src; const FrameDesc* desc;
+    const void* wgt; const float* bias;       // stem weights tiled with cin_store = 4 (k = tap*4 + c), 2 k-steps
+    void* out; int out_cs, out_co;
+    int tw, th, Ho, Wo, Cout, tiles_x;
+};
+hipError_t launch_stem_fused(const StemArgs& a, int n, hipStream_t s);
+int stem_tiles_x(int Wo);
+
 // kernels_head.hip -- fused Detect head (final 1x1 convs + DFL + dist2bbox + sigmoid + decode/threshold)
 struct HeadLevel {
     const void* box_in; const void* cls_in;   // [n][H*W][cs] activations of the two branches' second 3x3 convs
