@@ -55,6 +55,9 @@ def host_cores():
     return max(1, min(n, 64))
 
 
+FORCE_GATHER = os.environ.get("ZLY_BENCH_FORCE_GATHER") == "1"
+
+
 def run_steps(eng, frame_sets, batch, steps, slabs, stream_ptr, world, gather_out):
     """enqueue `steps` steps; with world > 1 all-gather each step's slabs, overlapped with the next."""
     import torch.distributed as dist
@@ -63,10 +66,10 @@ def run_steps(eng, frame_sets, batch, steps, slabs, stream_ptr, world, gather_ou
         d = frame_sets[k % len(frame_sets)]
         s = slabs[k % 2]
         eng.detect_device(d.data_ptr(), batch, 416, 416, d_slabs_ptr=s.data_ptr(), tag0=k * batch, stream=stream_ptr)
-        if world > 1:
+        if world > 1 or FORCE_GATHER:
             if len(works) >= 2:
                 works.pop(0).wait()                    # slab buffer k%2 is free again once its gather finished
-            works.append(shard.gather_slabs(s, world, out=gather_out[k % 2], async_op=True)[1])
+            works.append(dist.all_gather_into_tensor(gather_out[k % 2], s, async_op=True))
     for w in works:
         w.wait()
 
@@ -133,6 +136,22 @@ def cpu_baseline(frames_np, seconds=12.0):
 
 
 def main():
+    # The driver reads ONE JSON line from stdout.  Libraries underneath print there too (RCCL writes its
+    # version banner to stdout when the communicator is created), so everything but the final line is sent
+    # to stderr: fd 1 is pointed at fd 2 for the whole run and the result goes to the saved descriptor.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        line = run()
+    finally:
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+    if line is not None:
+        os.write(1, (line + "\n").encode())
+
+
+def run():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -153,15 +172,23 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
     torch.cuda.set_device(local_rank)
     import torch.distributed as dist
-    if world > 1:
+    force_gather = os.environ.get("ZLY_BENCH_FORCE_GATHER") == "1"     # rehearse the RCCL path on one GPU
+    if world > 1 or force_gather:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        if world == 1:
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     B = a.batch
     big = 64
     eng = zly.Engine(dtype=zly.DTYPE_BF16, max_batch=max(B, big), max_dets=64, device=local_rank, warmup_runs=3,
                      use_graph=not a.eager)
-    stream = torch.cuda.current_stream()
+    # a real (non-default) torch stream: the engine enqueues on it, and torch.distributed orders the RCCL
+    # all-gather of the slabs behind it (with the legacy default stream the engine would fall back to its
+    # own stream and the collective would not be ordered after NMS)
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
     sp = stream.cuda_stream
     n_sets = 4
     frames_np = zm.synth_frames(n_sets * big, 416, 416, seed=20250328 + rank, rects=False)
@@ -174,11 +201,12 @@ def main():
         return [torch.zeros(n * sb, dtype=torch.uint8, device="cuda") for _ in range(2)]
 
     def gather_bufs(n):
-        return [torch.zeros(world * n * sb, dtype=torch.uint8, device="cuda") for _ in range(2)] if world > 1 else None
+        return [torch.zeros(world * n * sb, dtype=torch.uint8, device="cuda") for _ in range(2)] if (world > 1 or force_gather) else None
 
     log(f"engine ready (rank {rank}/{world}), headline leg: batch {B} x {a.steps} steps")
     # ---- headline: BASELINE config[1] (batch B per GPU per step) -----------------------------------
-    dt = timed(eng, sets_b, B, a.steps, a.warmup, slab_bufs(B), sp, world, gather_bufs(B))
+    gb_head = gather_bufs(B)
+    dt = timed(eng, sets_b, B, a.steps, a.warmup, slab_bufs(B), sp, world, gb_head)
     value = world * B * a.steps / dt
     ms_per_step = dt / a.steps * 1e3
     result = {
@@ -258,13 +286,17 @@ def main():
         result["speedup_vs_cpu_baseline"] = round(value / result["cpu_baseline"]["value"], 1)
     st = eng.stats()
     result["engine_stats"] = {"inference_count": st["inference_count"], "inference_errors": st["inference_errors"]}
-    if world > 1:
+    if world > 1 or force_gather:
+        # the gathered slabs of the last headline step, back in global frame order, must be well-formed
+        g = shard.global_order(gb_head[(a.steps - 1) % 2], world * B, world, sb)
+        hd = g[:, :16].contiguous().view(torch.int32).cpu().numpy()
+        assert (hd[:, 0] >= 0).all() and (hd[:, 1] >= hd[:, 0]).all(), "malformed gathered slabs"
+        result["gather"] = {"ranks": world, "bytes_per_rank_per_step": B * sb, "frames_checked": int(hd.shape[0])}
         dist.barrier()
-    if rank == 0:
-        print(json.dumps(result), flush=True)
     eng.close()
-    if world > 1:
+    if world > 1 or force_gather:
         dist.destroy_process_group()
+    return json.dumps(result) if rank == 0 else None
 
 
 if __name__ == "__main__":
