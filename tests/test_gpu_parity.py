@@ -367,3 +367,51 @@ def test_model_file_errors(weights_path, tmp_path):
     with pytest.raises(zly.ZlyError) as ei:
         zly.Engine(str(bad))
     assert ei.value.code == zly.ERR_MODEL_LOAD
+
+
+# ---------------------------------------------------------------------------------------------------
+# the other BASELINE configurations as parity cases: 640x640 input (config 3) and YOLOv8-s widths (config 4, bf16)
+# ---------------------------------------------------------------------------------------------------
+def test_640x640_fp32_and_bf16(weights_path, oracle, ref_fp32):
+    frames = zm.synth_frames(2, 640, 640, seed=11, rects=False)
+    x = _pre(oracle, frames, 640, 640)
+    want = ref_fp32.forward(torch.from_numpy(x)).numpy()
+    assert want.shape == (2, 84, 8400)
+    e = zly.Engine(weights_path, model_w=640, model_h=640, dtype=zly.DTYPE_FP32, max_batch=2, max_dets=512, warmup_runs=0)
+    got = e.forward(x)
+    assert np.abs(got[:, :4] - want[:, :4]).max() <= 2 * FP32_BOX_TOL and np.abs(got[:, 4:] - want[:, 4:]).max() <= FP32_SCORE_TOL
+    e.close()
+    e = zly.Engine(weights_path, model_w=640, model_h=640, dtype=zly.DTYPE_BF16, max_batch=2, max_dets=512, warmup_runs=0)
+    for f in frames:
+        dets, n = e.detect(f, cap=512)
+        own = oracle.postprocess(e.head_tensor(0), 640, 640)
+        assert n == len(own) and det_fields_equal(dets, own[:512])
+    got = e.forward(x)
+    db, ds = got[:, :4] - want[:, :4], got[:, 4:] - want[:, 4:]
+    assert _rms(db) <= 1.6 * BF16_BOX_RMS and _rms(ds) <= BF16_SCORE_RMS            # boxes scale with the input size
+    e.close()
+
+
+def test_yolov8s_widths(tmp_path, oracle):
+    """YOLOv8-s channel widths (32..512, Detect class branch 128 wide): the plan builder, tile pickers and the
+    fused Detect tail are generic in the widths; the 32-channel stem takes the unfused preprocess + conv path."""
+    import yolov8_ref
+    spec = zm.build_spec("s")
+    p = str(tmp_path / "yolov8s_synth.zlyw")
+    zm.write_zlyw(p, spec, zm.synth_weights(spec, seed=9))
+    ref = yolov8_ref.load(p, "fp32")
+    frames = zm.synth_frames(2, 320, 320, seed=12, rects=False)
+    x = _pre(oracle, frames, 320, 320)
+    want = ref.forward(torch.from_numpy(x)).numpy()
+    e = zly.Engine(p, model_w=320, model_h=320, dtype=zly.DTYPE_FP32, max_batch=2, max_dets=512, warmup_runs=0)
+    got = e.forward(x)
+    scale = max(1.0, float(np.abs(want[:, :4]).max()) / 800.0)
+    assert np.abs(got[:, :4] - want[:, :4]).max() <= 4 * FP32_BOX_TOL * scale
+    assert np.abs(got[:, 4:] - want[:, 4:]).max() <= 2 * FP32_SCORE_TOL
+    e.close()
+    e = zly.Engine(p, model_w=320, model_h=320, dtype=zly.DTYPE_BF16, max_batch=2, max_dets=512, conf_thr=0.05, warmup_runs=0)
+    for f in frames:
+        dets, n = e.detect(f, cap=512)
+        own = oracle.postprocess(e.head_tensor(0), 320, 320, 0.05, 0.45)
+        assert n == len(own) and det_fields_equal(dets, own[:512])
+    e.close()
