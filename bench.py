@@ -274,6 +274,13 @@ def run():
                             gf, mb = o["flops"] * nb / 1e9, o["bytes"] * nb / 1e6
                             f.write(f"{o['name']:44s} {o['kind']:4d} {m:9.4f} {gf:9.3f} {mb:9.2f} {gf / max(m, 1e-9):9.2f} {mb / max(m, 1e-9):9.1f}\n")
                         f.write(f"{'TOTAL':44s} {'':4s} {float(ms.sum()):9.4f}\n\n")
+            # HBM-side traffic of the same kernels from the PMC counters (collected off-line with rocprofv3, two
+            # --pmc passes, gfx950 correction applied; see the file for provenance): per batch-64 step
+            tpath = os.path.join(ROOT, "profiles", "r01_traffic_b64.json")
+            if B == 64 and os.path.exists(tpath):
+                tj = json.load(open(tpath))
+                roof[B]["traffic"] = tj["traffic_bytes_per_step"]
+                roof[B]["traffic_note"] = "bytes per step from " + os.path.relpath(tpath, ROOT) + ": " + tj["correction"]
             result["roofline"] = roof[B]
             if B != 1:
                 result["roofline_b1"] = roof[1]

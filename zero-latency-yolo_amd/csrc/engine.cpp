@@ -19,6 +19,7 @@
 #include <vector>
 #include <string.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 namespace zly {
 
@@ -50,6 +51,7 @@ struct Op {
     std::string name;
     // conv
     View in{-1, 0, 0}, out{-1, 0, 0}, res{-1, 0, 0};
+    View in2{-1, 0, 0};                // 1x1 convs: second (full-size) source of a fused Upsample+Concat input; `in` is then half-size
     int ks = 1, stride = 1, act = 0, out_f32 = 0;
     int cout = 0, cout_pad = 0, nk = 0, K = 0;
     size_t w_off = 0, b_off = 0;       // offsets into the device weight blob
@@ -136,7 +138,7 @@ struct PlanBuilder {
         memcpy(blob.data() + off, p, bytes);
         return off;
     }
-    bool conv(const std::vector<std::string>& names, View in, View out, View res = View{-1, 0, 0}, bool out_f32 = false) {
+    bool conv(const std::vector<std::string>& names, View in, View out, View res = View{-1, 0, 0}, bool out_f32 = false, View in2 = View{-1, 0, 0}) {
         std::vector<const ConvRec*> srcs;
         for (const std::string& n : names) {
             const ConvRec* r = e->model.find(n);
@@ -149,22 +151,29 @@ struct PlanBuilder {
         const Buffer& ib = e->bufs[(size_t)in.buf];
         const Buffer& ob = e->bufs[(size_t)out.buf];
         const int epl = e->dtype == ZLY_DTYPE_BF16 ? 8 : 4;
-        if (in.C < r0->cin || in.C % epl != 0 || in.co % epl != 0 || ib.C % epl != 0 || in.co + in.C > ib.C) { err = "bad input view for " + names[0]; return false; }
+        const int cin_total = in.C + (in2.buf >= 0 ? in2.C : 0);
+        if (cin_total < r0->cin || in.C % epl != 0 || in.co % epl != 0 || ib.C % epl != 0 || in.co + in.C > ib.C) { err = "bad input view for " + names[0]; return false; }
+        if (in2.buf >= 0) {
+            const Buffer& i2 = e->bufs[(size_t)in2.buf];
+            if (r0->k != 1 || in.C % kstep != 0 || in2.C % epl != 0 || in2.co % epl != 0 || i2.C % epl != 0 || in2.co + in2.C > i2.C ||
+                i2.H != ob.H || i2.W != ob.W || ib.H * 2 != ob.H || ib.W * 2 != ob.W) { err = "bad upsample+concat input for " + names[0]; return false; }
+        }
         Op op;
         op.kind = OP_CONV;
         op.name = names[0];
         for (size_t i = 1; i < names.size(); ++i) op.name += "+" + names[i];
         if (op.name.size() > 47) op.name.resize(47);
-        op.in = in; op.out = out; op.res = res;
+        op.in = in; op.out = out; op.res = res; op.in2 = in2;
         op.ks = r0->k; op.stride = r0->stride; op.act = r0->act; op.out_f32 = out_f32 ? 1 : 0;
         std::vector<uint8_t> w;
         std::vector<float> b;
-        repack_conv(srcs, in.C, kstep, e->dtype == ZLY_DTYPE_BF16, &w, &b, &op.cout, &op.cout_pad, &op.nk);
+        repack_conv(srcs, cin_total, kstep, e->dtype == ZLY_DTYPE_BF16, &w, &b, &op.cout, &op.cout_pad, &op.nk);
         if (out.C != op.cout || out.co % 4 != 0 || ob.C % 4 != 0 || out.co + out.C > ob.C) { err = "bad output view for " + names[0]; return false; }
         if (out_f32 != ob.f32) { err = "output dtype mismatch for " + names[0]; return false; }
         const int Ho = ob.H, Wo = ob.W;
-        if (Ho != (ib.H + 2 * (op.ks / 2) - op.ks) / op.stride + 1 || Wo != (ib.W + 2 * (op.ks / 2) - op.ks) / op.stride + 1) { err = "spatial mismatch for " + names[0]; return false; }
-        op.K = op.ks * op.ks * in.C;
+        const int Hin = in2.buf >= 0 ? ib.H * 2 : ib.H, Win = in2.buf >= 0 ? ib.W * 2 : ib.W;
+        if (Ho != (Hin + 2 * (op.ks / 2) - op.ks) / op.stride + 1 || Wo != (Win + 2 * (op.ks / 2) - op.ks) / op.stride + 1) { err = "spatial mismatch for " + names[0]; return false; }
+        op.K = op.ks * op.ks * cin_total;
         op.w_off = append(w.data(), w.size());
         op.b_off = append(b.data(), b.size() * sizeof(float));
         int co = 0;
@@ -176,7 +185,7 @@ struct PlanBuilder {
         }
         op.flops = 2.0 * macs;
         const double osz = out_f32 ? 4.0 : (double)e->esz;
-        op.bytes = (double)ib.H * ib.W * r0->cin * e->esz + (double)Ho * Wo * op.cout * osz +
+        op.bytes = ((double)ib.H * ib.W * in.C + (in2.buf >= 0 ? (double)Ho * Wo * in2.C : 0.0)) * e->esz * ((double)r0->cin / cin_total) + (double)Ho * Wo * op.cout * osz +
                    (double)op.cout * r0->cin * op.ks * op.ks * e->esz + (res.buf >= 0 ? (double)Ho * Wo * op.cout * e->esz : 0.0);
         e->ops.push_back(op);
         for (size_t i = 0; i < names.size(); ++i) e->tap_index[names[i]] = std::make_pair((int)e->ops.size() - 1, (int)i);
@@ -196,10 +205,10 @@ struct PlanBuilder {
     }
     // C2f(c1 -> c2, n bottlenecks): cv1 writes [0,2c) of the concat buffer, bottleneck i reads
     // [(1+i)c,(2+i)c) and writes [(2+i)c,(3+i)c), cv2 reads all (2+n)c channels.
-    bool c2f(const std::string& p, View in, View out, int n, bool shortcut, int H, int W) {
+    bool c2f(const std::string& p, View in, View out, int n, bool shortcut, int H, int W, View in2 = View{-1, 0, 0}) {
         const int c = out.C / 2;
         const int cat = add_buffer(p + ".cat", H, W, (2 + n) * c);
-        if (!conv({p + ".cv1"}, in, View{cat, 0, 2 * c})) return false;
+        if (!conv({p + ".cv1"}, in, View{cat, 0, 2 * c}, View{-1, 0, 0}, false, in2)) return false;
         for (int i = 0; i < n; ++i) {
             const View src{cat, (1 + i) * c, c};
             const std::string m = p + ".m." + std::to_string(i);
@@ -268,19 +277,10 @@ static int build_plan(zly_engine* e, std::string* err)
         e->ops.push_back(p);
     }
     ok = ok && pb.conv({"model.9.cv2"}, View{spp, 0, 2 * ch[4]}, View{cat20, ch[3], ch[4]});                     // P5 -> cat20
-    // neck, top-down
-    if (ok) {
-        Op u; u.kind = OP_UPSAMPLE; u.name = "model.10.upsample"; u.in = View{cat20, ch[3], ch[4]}; u.out = View{cat11, 0, ch[4]}; u.c = ch[4];
-        u.bytes = (double)H32 * W32 * ch[4] * e->esz * 5;
-        e->ops.push_back(u);
-    }
-    ok = ok && pb.c2f("model.12", View{cat11, 0, ch[4] + ch[3]}, View{cat17, ch[2], ch[3]}, nb[4], false, H16, W16);
-    if (ok) {
-        Op u; u.kind = OP_UPSAMPLE; u.name = "model.13.upsample"; u.in = View{cat17, ch[2], ch[3]}; u.out = View{cat14, 0, ch[3]}; u.c = ch[3];
-        u.bytes = (double)H16 * W16 * ch[3] * e->esz * 5;
-        e->ops.push_back(u);
-    }
-    ok = ok && pb.c2f("model.15", View{cat14, 0, ch[3] + ch[2]}, View{a15, 0, ch[2]}, nb[5], false, H8, W8);
+    // neck, top-down.  Upsample(x2, nearest) + Concat are fused into the consumer: model.12.cv1 / model.15.cv1 read
+    // their first channels from the half-size tensor at (y>>1, x>>1) and the rest from the skip tensor.
+    ok = ok && pb.c2f("model.12", View{cat20, ch[3], ch[4]}, View{cat17, ch[2], ch[3]}, nb[4], false, H16, W16, View{cat11, ch[4], ch[3]});
+    ok = ok && pb.c2f("model.15", View{cat17, ch[2], ch[3]}, View{a15, 0, ch[2]}, nb[5], false, H8, W8, View{cat14, ch[3], ch[2]});
     // neck, bottom-up
     ok = ok && pb.conv({"model.16"}, View{a15, 0, ch[2]}, View{cat17, 0, ch[2]});
     ok = ok && pb.c2f("model.18", View{cat17, 0, ch[2] + ch[3]}, View{a18, 0, ch[3]}, nb[6], false, H16, W16);
@@ -412,8 +412,14 @@ static hipError_t run_op(zly_engine* e, const Op& op, int n, const uint8_t* d_sr
         else { a.res = nullptr; a.res_cs = 0; a.res_co = 0; }
         a.stride = op.stride; a.pad = op.ks / 2;
         a.K = op.K; a.nk = op.nk; a.M = n * ob.H * ob.W; a.act = op.act; a.out_f32 = op.out_f32;
+        a.in2 = nullptr; a.in2_cs = 0; a.in2_co = 0; a.split_c = 0;
+        if (op.in2.buf >= 0) {
+            const Buffer& i2 = e->bufs[(size_t)op.in2.buf];
+            a.in2 = i2.ptr; a.in2_cs = i2.C; a.in2_co = op.in2.co; a.split_c = op.in.C;
+            a.H = ob.H; a.W = ob.W; a.Cin = op.in.C + op.in2.C;        // logical (full-size, concatenated) input
+        }
         ConvLaunch cfg;
-        conv_pick_config(e->dtype, op.ks, op.stride, op.in.C, op.cout_pad, n, ob.H, ob.W, &cfg);
+        conv_pick_config(e->dtype, op.ks, op.stride, a.Cin, op.cout_pad, n, ob.H, ob.W, &cfg);
         return launch_conv(e->dtype, a, cfg, s);
     }
     case OP_SPPF: {
@@ -955,18 +961,25 @@ int32_t zly_profile_ops(zly_engine* e, int32_t n, const void* d_frames, int32_t 
     for (hipEvent_t& x : ev) HIP_TRY(hipEventCreate(&x), ZLY_ERR_SYSTEM);
     std::vector<double> acc(nops, 0.0);
     int rcode = ZLY_OK;
+    // ZLY_PROFILE_INNER=k: every op is launched k times back to back between its two events, and the time is
+    // divided by k -- the in-sequence cost of a launch (kernel + boundary) without the ~5 us that an event pair
+    // per launch adds; used to study the batch-1 path, where most kernels are shorter than that
+    int inner = 1;
+    if (const char* v = getenv("ZLY_PROFILE_INNER")) inner = atoi(v) > 0 ? atoi(v) : 1;
     for (int r = 0; r < reps && rcode == ZLY_OK; ++r) {
         hipEventRecord(ev[0], e->stream);
         for (size_t i = 0; i < nops; ++i) {
             hipError_t hr = hipSuccess;
-            if (e->stem_fused && i == 0) {
-                // shipped path: preprocess is part of the stem kernel; its time is booked on ops[1] (model.0)
-            } else if (e->stem_fused && i == 1) {
-                StemArgs st = e->stem;
-                st.src = (const uint8_t*)d_frames; st.desc = e->d_desc;
-                hr = launch_stem_fused(st, n, e->stream);
-            } else {
-                hr = run_op(e, e->ops[i], n, (const uint8_t*)d_frames, nullptr, 0, e->stream);
+            for (int k = 0; k < inner && hr == hipSuccess; ++k) {
+                if (e->stem_fused && i == 0) {
+                    // shipped path: preprocess is part of the stem kernel; its time is booked on ops[1] (model.0)
+                } else if (e->stem_fused && i == 1) {
+                    StemArgs st = e->stem;
+                    st.src = (const uint8_t*)d_frames; st.desc = e->d_desc;
+                    hr = launch_stem_fused(st, n, e->stream);
+                } else {
+                    hr = run_op(e, e->ops[i], n, (const uint8_t*)d_frames, nullptr, 0, e->stream);
+                }
             }
             if (hr != hipSuccess) { rcode = fail(ZLY_ERR_INFERENCE, std::string("profile: ") + hipGetErrorString(hr)); break; }
             hipEventRecord(ev[i + 1], e->stream);
@@ -976,7 +989,7 @@ int32_t zly_profile_ops(zly_engine* e, int32_t n, const void* d_frames, int32_t 
         for (size_t i = 0; i < nops; ++i) {
             float ms = 0.f;
             hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
-            acc[i] += ms;
+            acc[i] += ms / inner;
         }
     }
     for (hipEvent_t& x : ev) hipEventDestroy(x);

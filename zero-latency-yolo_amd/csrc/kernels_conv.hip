@@ -98,8 +98,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
 
     const T* __restrict__ in = static_cast<const T*>(a.in);
 
-    int boff[PT], iy0[PT], ix0[PT];
+    int boff[PT], iy0[PT], ix0[PT], boff2[PT];
     bool mval[PT];
+    const bool dual = MODE == 0 && a.in2 != nullptr;
+    const T* __restrict__ in2 = static_cast<const T*>(a.in2);
 #pragma unroll
     for (int t = 0; t < PT; ++t) {
         const int m = m_base + t * 16 + p;
@@ -112,6 +114,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
         iy0[t] = oy * a.stride - a.pad;
         ix0[t] = ox * a.stride - a.pad;
         boff[t] = ((b * a.H + iy0[t]) * a.W + ix0[t]) * a.in_cs + a.in_co;
+        boff2[t] = 0;
+        if (dual) {     // 1x1, stride 1: (iy, ix) = (oy, ox); `in` is the half-size tensor
+            boff[t] = ((b * (a.H >> 1) + (oy >> 1)) * (a.W >> 1) + (ox >> 1)) * a.in_cs + a.in_co;
+            boff2[t] = ((b * a.H + oy) * a.W + ox) * a.in2_cs + a.in2_co - a.split_c;
+        }
     }
 
     f32x4 acc[CT][PT];
@@ -153,7 +160,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
             F z;
 #pragma unroll
             for (int j = 0; j < EPL; ++j) z[j] = (T)0.0f;
-            af[t] = ok ? *reinterpret_cast<const F*>(in + (long)(boff[t] + koff)) : z;
+            const T* src = (dual && ci >= a.split_c) ? in2 + (long)(boff2[t] + koff) : in + (long)(boff[t] + koff);
+            af[t] = ok ? *reinterpret_cast<const F*>(src) : z;
         }
     };
     auto mma_all = [&](const F (&wf)[CT], const F (&af)[PT]) {

@@ -79,56 +79,83 @@ hipError_t launch_nchw_to_nhwc8(int dtype, const float* in_nchw, void* out_nhwc8
 }
 
 // ------------------------------------------------------------------------------------------------
-// SPPF: three chained 5x5 stride-1 max-pools (pad 2, -inf outside).  The source is channel block 0
-// ([0,c)) of the SPPF concat buffer; pools 1..3 are written to channel blocks 1..3 of the same buffer,
-// so the following 1x1 conv reads the 4c-channel concat without a Concat op.
-// One workgroup = one frame x 8 channels: the HxWx8 tile lives in LDS as fp32 (max is exact on
-// bf16 values), each pool is a separable row pass + column pass between two LDS images.
+// SPPF: three chained 5x5 stride-1 max-pools (pad 2, -inf outside).  k chained 5x5 pools are one max over
+// a (4k+1)^2 window clipped to the map, so pool1/2/3 = windows of radius 2/4/6, and the max is separable.
+// The source is channel block 0 ([0,c)) of the SPPF concat buffer; the three pools are written to channel
+// blocks 1..3 of the same buffer, so the following 1x1 conv reads the 4c-channel concat without a Concat op.
+// One workgroup = one frame x 8 channels, tile in LDS as fp32 (max is exact on bf16 values):
+//   row pass   : every element gets its running row maxima of radius 2, 4 and 6 (13 LDS reads, cumulative)
+//   column pass: radius-r column max over the radius-r row maxima (5 + 9 + 13 reads), stored straight out.
+// Two barriers in total (the chained formulation needed seven).
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void sppf_pool_kernel(T* __restrict__ buf, int cs, int c, int H, int W)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* A = lds;
-    float* B = lds + (size_t)H * W * 8;
-    const int f = blockIdx.y, c0 = blockIdx.x * 8;
     const int hw = H * W, total = hw * 8;
+    float* A = lds;                       // source tile
+    float* R2 = lds + (size_t)total;      // row maxima, radius 2 / 4 / 6
+    float* R4 = R2 + (size_t)total;
+    float* R6 = R4 + (size_t)total;
+    const int f = blockIdx.y, c0 = blockIdx.x * 8;
     T* base = buf + (size_t)f * hw * cs;
     for (int e = threadIdx.x; e < total; e += 256) {
         const int px = e >> 3, ch = e & 7;
         A[e] = (float)base[(size_t)px * cs + c0 + ch];
     }
     __syncthreads();
-    for (int pool = 1; pool <= 3; ++pool) {
-        for (int e = threadIdx.x; e < total; e += 256) {          // row pass A -> B
-            const int px = e >> 3, ch = e & 7;
-            const int y = px / W, x = px - y * W;
-            float m = -INFINITY;
-            for (int dx = -2; dx <= 2; ++dx) {
-                const int xx = x + dx;
-                if (xx >= 0 && xx < W) m = fmaxf(m, A[((y * W + xx) << 3) + ch]);
-            }
-            B[e] = m;
+    for (int e = threadIdx.x; e < total; e += 256) {
+        const int px = e >> 3, ch = e & 7;
+        const int y = px / W, x = px - y * W;
+        const float* row = A + ((y * W) << 3) + ch;
+        float m = row[x << 3];
+#pragma unroll
+        for (int d = 1; d <= 2; ++d) {
+            if (x - d >= 0) m = fmaxf(m, row[(x - d) << 3]);
+            if (x + d < W) m = fmaxf(m, row[(x + d) << 3]);
         }
-        __syncthreads();
-        for (int e = threadIdx.x; e < total; e += 256) {          // column pass B -> A, and store
-            const int px = e >> 3, ch = e & 7;
-            const int y = px / W, x = px - y * W;
-            float m = -INFINITY;
-            for (int dy = -2; dy <= 2; ++dy) {
-                const int yy = y + dy;
-                if (yy >= 0 && yy < H) m = fmaxf(m, B[((yy * W + x) << 3) + ch]);
-            }
-            A[e] = m;
-            base[(size_t)px * cs + pool * c + c0 + ch] = (T)m;
+        R2[e] = m;
+#pragma unroll
+        for (int d = 3; d <= 4; ++d) {
+            if (x - d >= 0) m = fmaxf(m, row[(x - d) << 3]);
+            if (x + d < W) m = fmaxf(m, row[(x + d) << 3]);
         }
-        __syncthreads();
+        R4[e] = m;
+#pragma unroll
+        for (int d = 5; d <= 6; ++d) {
+            if (x - d >= 0) m = fmaxf(m, row[(x - d) << 3]);
+            if (x + d < W) m = fmaxf(m, row[(x + d) << 3]);
+        }
+        R6[e] = m;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < total; e += 256) {
+        const int px = e >> 3, ch = e & 7;
+        const int y = px / W, x = px - y * W;
+        const int col = (x << 3) + ch, pitch = W << 3;
+        float m2 = R2[e], m4 = R4[e], m6 = R6[e];
+#pragma unroll
+        for (int d = 1; d <= 6; ++d) {
+            const bool up = y - d >= 0, dn = y + d < H;
+            if (d <= 2) {
+                if (up) m2 = fmaxf(m2, R2[(y - d) * pitch + col]);
+                if (dn) m2 = fmaxf(m2, R2[(y + d) * pitch + col]);
+            }
+            if (d <= 4) {
+                if (up) m4 = fmaxf(m4, R4[(y - d) * pitch + col]);
+                if (dn) m4 = fmaxf(m4, R4[(y + d) * pitch + col]);
+            }
+            if (up) m6 = fmaxf(m6, R6[(y - d) * pitch + col]);
+            if (dn) m6 = fmaxf(m6, R6[(y + d) * pitch + col]);
+        }
+        T* o = base + (size_t)px * cs + c0 + ch;
+        o[c] = (T)m2; o[2 * c] = (T)m4; o[3 * c] = (T)m6;
     }
 }
 
 hipError_t launch_sppf_pool(int dtype, void* buf, int cs, int c, int n, int H, int W, hipStream_t s)
 {
-    const size_t lds = (size_t)H * W * 8 * sizeof(float) * 2;
+    const size_t lds = (size_t)H * W * 8 * sizeof(float) * 4;
     if (lds > 160 * 1024 || (c % 8) != 0) return hipErrorInvalidValue;
     dim3 grid(c / 8, n);
     if (dtype == ZLY_DTYPE_BF16) {

@@ -33,6 +33,10 @@ struct ConvArgs {
     int M;                        // batch*Ho*Wo
     int act;                      // 1 = SiLU
     int out_f32;                  // 1 = write fp32 regardless of the activation dtype
+    // 1x1 convs only: fused "nearest-2x Upsample + Concat" input (yolov8.yaml layers 10-11, 13-14).  When in2 is
+    // set, input channels [0, split_c) are read from `in`, a tensor of HALF the spatial size, at (y>>1, x>>1),
+    // and channels [split_c, Cin) from `in2` at full size.  split_c is a multiple of the k-step.
+    const void* in2;  int in2_cs, in2_co, split_c;
 };
 
 struct ConvLaunch { int ks, ct, pt, fastk, ksplit, lds; };
