@@ -88,68 +88,79 @@ hipError_t launch_nchw_to_nhwc8(int dtype, const float* in_nchw, void* out_nhwc8
 //   column pass: radius-r column max over the radius-r row maxima (5 + 9 + 13 reads), stored straight out.
 // Two barriers in total (the chained formulation needed seven).
 // ------------------------------------------------------------------------------------------------
+// 8 channels of one pixel as two float4 (one thread = one pixel: 16-byte global accesses, b128 LDS accesses)
+struct Px8 { f32x4 lo, hi; };
+__device__ __forceinline__ Px8 px_max(Px8 a, const Px8& b) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { a.lo[j] = fmaxf(a.lo[j], b.lo[j]); a.hi[j] = fmaxf(a.hi[j], b.hi[j]); }
+    return a;
+}
+__device__ __forceinline__ Px8 load_px8(const bf16_t* p) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+    Px8 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { o.lo[j] = (float)v[j]; o.hi[j] = (float)v[4 + j]; }
+    return o;
+}
+__device__ __forceinline__ Px8 load_px8(const float* p) {
+    Px8 o; o.lo = *reinterpret_cast<const f32x4*>(p); o.hi = *reinterpret_cast<const f32x4*>(p + 4); return o;
+}
+__device__ __forceinline__ void store_px8(bf16_t* p, const Px8& v) {
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { o[j] = (bf16_t)v.lo[j]; o[4 + j] = (bf16_t)v.hi[j]; }
+    *reinterpret_cast<bf16x8*>(p) = o;
+}
+__device__ __forceinline__ void store_px8(float* p, const Px8& v) {
+    *reinterpret_cast<f32x4*>(p) = v.lo; *reinterpret_cast<f32x4*>(p + 4) = v.hi;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void sppf_pool_kernel(T* __restrict__ buf, int cs, int c, int H, int W)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int hw = H * W, total = hw * 8;
-    float* A = lds;                       // source tile
-    float* R2 = lds + (size_t)total;      // row maxima, radius 2 / 4 / 6
-    float* R4 = R2 + (size_t)total;
-    float* R6 = R4 + (size_t)total;
+    const int hw = H * W;
+    Px8* A = reinterpret_cast<Px8*>(lds);       // source tile
+    Px8* R2 = A + hw;                           // row maxima, radius 2 / 4 / 6
+    Px8* R4 = R2 + hw;
+    Px8* R6 = R4 + hw;
     const int f = blockIdx.y, c0 = blockIdx.x * 8;
-    T* base = buf + (size_t)f * hw * cs;
-    for (int e = threadIdx.x; e < total; e += 256) {
-        const int px = e >> 3, ch = e & 7;
-        A[e] = (float)base[(size_t)px * cs + c0 + ch];
+    T* base = buf + (size_t)f * hw * cs + c0;
+    for (int px = threadIdx.x; px < hw; px += 256) A[px] = load_px8(base + (size_t)px * cs);
+    __syncthreads();
+    for (int px = threadIdx.x; px < hw; px += 256) {
+        const int y = px / W, x = px - y * W;
+        const Px8* row = A + y * W;
+        Px8 m = row[x];
+#pragma unroll
+        for (int d = 1; d <= 6; ++d) {
+            if (x - d >= 0) m = px_max(m, row[x - d]);
+            if (x + d < W) m = px_max(m, row[x + d]);
+            if (d == 2) R2[px] = m;
+            if (d == 4) R4[px] = m;
+        }
+        R6[px] = m;
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < total; e += 256) {
-        const int px = e >> 3, ch = e & 7;
+    for (int px = threadIdx.x; px < hw; px += 256) {
         const int y = px / W, x = px - y * W;
-        const float* row = A + ((y * W) << 3) + ch;
-        float m = row[x << 3];
-#pragma unroll
-        for (int d = 1; d <= 2; ++d) {
-            if (x - d >= 0) m = fmaxf(m, row[(x - d) << 3]);
-            if (x + d < W) m = fmaxf(m, row[(x + d) << 3]);
-        }
-        R2[e] = m;
-#pragma unroll
-        for (int d = 3; d <= 4; ++d) {
-            if (x - d >= 0) m = fmaxf(m, row[(x - d) << 3]);
-            if (x + d < W) m = fmaxf(m, row[(x + d) << 3]);
-        }
-        R4[e] = m;
-#pragma unroll
-        for (int d = 5; d <= 6; ++d) {
-            if (x - d >= 0) m = fmaxf(m, row[(x - d) << 3]);
-            if (x + d < W) m = fmaxf(m, row[(x + d) << 3]);
-        }
-        R6[e] = m;
-    }
-    __syncthreads();
-    for (int e = threadIdx.x; e < total; e += 256) {
-        const int px = e >> 3, ch = e & 7;
-        const int y = px / W, x = px - y * W;
-        const int col = (x << 3) + ch, pitch = W << 3;
-        float m2 = R2[e], m4 = R4[e], m6 = R6[e];
+        Px8 m2 = R2[px], m4 = R4[px], m6 = R6[px];
 #pragma unroll
         for (int d = 1; d <= 6; ++d) {
             const bool up = y - d >= 0, dn = y + d < H;
             if (d <= 2) {
-                if (up) m2 = fmaxf(m2, R2[(y - d) * pitch + col]);
-                if (dn) m2 = fmaxf(m2, R2[(y + d) * pitch + col]);
+                if (up) m2 = px_max(m2, R2[(y - d) * W + x]);
+                if (dn) m2 = px_max(m2, R2[(y + d) * W + x]);
             }
             if (d <= 4) {
-                if (up) m4 = fmaxf(m4, R4[(y - d) * pitch + col]);
-                if (dn) m4 = fmaxf(m4, R4[(y + d) * pitch + col]);
+                if (up) m4 = px_max(m4, R4[(y - d) * W + x]);
+                if (dn) m4 = px_max(m4, R4[(y + d) * W + x]);
             }
-            if (up) m6 = fmaxf(m6, R6[(y - d) * pitch + col]);
-            if (dn) m6 = fmaxf(m6, R6[(y + d) * pitch + col]);
+            if (up) m6 = px_max(m6, R6[(y - d) * W + x]);
+            if (dn) m6 = px_max(m6, R6[(y + d) * W + x]);
         }
-        T* o = base + (size_t)px * cs + c0 + ch;
-        o[c] = (T)m2; o[2 * c] = (T)m4; o[3 * c] = (T)m6;
+        T* o = base + (size_t)px * cs;
+        store_px8(o + c, m2); store_px8(o + 2 * c, m4); store_px8(o + 3 * c, m6);
     }
 }
 
