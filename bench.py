@@ -246,8 +246,12 @@ def run():
             log("roofline leg (per-op hipEvent profile)")
             ops = eng.ops()
             roof = {}
+            # every forward launch is issued 8x back to back between its event pair and the time divided by 8: an
+            # event pair around a single launch adds several microseconds to it, which at ~10-20 us per launch
+            # is not negligible; this way the per-launch figure is kernel + launch boundary, as rocprofv3 sees it
+            os.environ["ZLY_PROFILE_INNER"] = "8"
             for nb, frames in ((B, sets_b[0]), (1, sets_1[0])):
-                ms = eng.profile_ops(frames.data_ptr(), nb, 416, 416, reps=20)
+                ms = eng.profile_ops(frames.data_ptr(), nb, 416, 416, reps=10)
                 conv = [(o, m) for o, m in zip(ops, ms) if o["kind"] == 1]
                 conv_ms = float(sum(m for _, m in conv))
                 flops = sum(o["flops"] for o, _ in conv) * nb
@@ -265,7 +269,7 @@ def run():
                             "all_ops_ms_per_step": round(float(ms.sum()), 4),
                             "other_ops_ms": {o["name"]: round(float(m), 4) for o, m in zip(ops, ms) if o["kind"] != 1},
                             "slowest_convs_ms": {o["name"]: round(float(m), 4) for o, m in top},
-                            "method": "mean of 20 eager passes with a hipEvent pair around every launch on the engine's stream (zly_profile_ops)"}
+                            "method": "zly_profile_ops: 20 eager passes on the engine's stream, each launch issued 8x back to back between a hipEvent pair, time / 8"}
                 if a.dump_ops:
                     with open(a.dump_ops, "a") as f:
                         f.write(f"# batch {nb}: per-op mean ms over 20 eager reps (hipEvents around every launch)\n")

@@ -107,7 +107,7 @@ typedef struct zly_stats {
 
 typedef struct zly_op_info {
     char name[48];
-    int32_t kind;          /* 0 preprocess, 1 conv, 2 sppf-pool, 3 upsample, 4 fused detect head (+decode), 6 nms */
+    int32_t kind;          /* 0 preprocess, 1 conv (incl. fused upsample+concat inputs), 2 sppf-pool, 4 fused detect tail (+decode), 6 nms */
     int32_t pad_;
     double flops_per_frame;   /* 2*MAC, algorithmic */
     double bytes_per_frame;   /* algorithmic: input read once + output written once + weights */

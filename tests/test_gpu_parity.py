@@ -415,3 +415,32 @@ def test_yolov8s_widths(tmp_path, oracle):
         own = oracle.postprocess(e.head_tensor(0), 320, 320, 0.05, 0.45)
         assert n == len(own) and det_fields_equal(dets, own[:512])
     e.close()
+
+
+def test_one_handle_from_several_host_threads(eng16):
+    """The reference calls submitInference from the UDP thread while the monitor thread polls getStatus
+    (SURVEY.md section 8b); one zly_engine handle must serialise concurrent callers and give each its own result."""
+    import threading
+    frames = [zm.synth_frames(1, 416, 416, seed=100 + i, rects=False)[0] for i in range(6)]
+    serial = [eng16.detect(f, cap=256) for f in frames]
+    errors_before = eng16.stats()["inference_errors"]
+    results, errors = {}, []
+
+    def worker(tid):
+        try:
+            for rep in range(5):
+                for i in range(tid, len(frames), 3):
+                    results[(tid, rep, i)] = eng16.detect(frames[i], cap=256)
+                    eng16.stats()
+        except Exception as exc:          # pragma: no cover
+            errors.append(exc)
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors
+    for (tid, rep, i), (dets, n) in results.items():
+        assert n == serial[i][1] and det_fields_equal(dets, serial[i][0])
+    assert eng16.stats()["inference_errors"] == errors_before

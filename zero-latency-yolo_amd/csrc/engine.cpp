@@ -44,7 +44,7 @@ struct Buffer {
     size_t elems_per_frame() const { return (size_t)H * W * C; }
 };
 
-enum OpKind { OP_PREPROCESS = 0, OP_CONV = 1, OP_SPPF = 2, OP_UPSAMPLE = 3, OP_HEAD = 4, OP_DECODE = 5, OP_NMS = 6 };
+enum OpKind { OP_PREPROCESS = 0, OP_CONV = 1, OP_SPPF = 2, OP_HEAD = 4, OP_NMS = 6 };
 
 struct Op {
     int kind = 0;
@@ -426,11 +426,6 @@ static hipError_t run_op(zly_engine* e, const Op& op, int n, const uint8_t* d_sr
         const Buffer& b = e->bufs[(size_t)op.in.buf];
         return launch_sppf_pool(e->dtype, b.ptr, b.C, op.c, n, b.H, b.W, s);
     }
-    case OP_UPSAMPLE: {
-        const Buffer& ib = e->bufs[(size_t)op.in.buf];
-        const Buffer& ob = e->bufs[(size_t)op.out.buf];
-        return launch_upsample2x(e->dtype, ib.ptr, ib.C, op.in.co, ob.ptr, ob.C, op.out.co, op.c, n, ib.H, ib.W, s);
-    }
     case OP_HEAD: {
         HeadArgs h = op.head;
         h.head = e->d_head; h.desc = e->d_desc; h.conf_thr = e->cfg.conf_thr; h.cand = e->d_cand; h.cand_count = e->d_count;
@@ -524,8 +519,9 @@ static int set_desc(zly_engine* e, int n, const int32_t* w, const int32_t* h, co
     for (int i = 0; i < n && same; ++i)
         same = e->desc_cache[(size_t)i].w == w[i] && e->desc_cache[(size_t)i].h == h[i] && e->desc_cache[(size_t)i].src_off == offs[i];
     if (same) return ZLY_OK;
-    // the pinned mirror may still be in flight from the previous call on another stream
-    HIP_TRY(hipStreamSynchronize(e->stream), ZLY_ERR_INFERENCE);
+    // rare path (frame sizes changed): the pinned mirror may still be in flight from a previous call, possibly
+    // on a caller-owned stream, so wait for the whole device before rewriting it
+    HIP_TRY(hipDeviceSynchronize(), ZLY_ERR_INFERENCE);
     if ((int)e->desc_cache.size() < n) e->desc_cache.resize((size_t)n);
     for (int i = 0; i < n; ++i) {
         FrameDesc d; d.src_off = offs[i]; d.w = w[i]; d.h = h[i];
@@ -970,7 +966,9 @@ int32_t zly_profile_ops(zly_engine* e, int32_t n, const void* d_frames, int32_t 
         hipEventRecord(ev[0], e->stream);
         for (size_t i = 0; i < nops; ++i) {
             hipError_t hr = hipSuccess;
-            for (int k = 0; k < inner && hr == hipSuccess; ++k) {
+            // only the idempotent forward ops are repeated: the Detect tail appends candidates and NMS consumes them
+            const int reps_i = (e->ops[i].kind == OP_HEAD || e->ops[i].kind == OP_NMS) ? 1 : inner;
+            for (int k = 0; k < reps_i && hr == hipSuccess; ++k) {
                 if (e->stem_fused && i == 0) {
                     // shipped path: preprocess is part of the stem kernel; its time is booked on ops[1] (model.0)
                 } else if (e->stem_fused && i == 1) {
@@ -989,7 +987,7 @@ int32_t zly_profile_ops(zly_engine* e, int32_t n, const void* d_frames, int32_t 
         for (size_t i = 0; i < nops; ++i) {
             float ms = 0.f;
             hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
-            acc[i] += ms / inner;
+            acc[i] += ms / ((e->ops[i].kind == OP_HEAD || e->ops[i].kind == OP_NMS) ? 1 : inner);
         }
     }
     for (hipEvent_t& x : ev) hipEventDestroy(x);

@@ -1,6 +1,7 @@
-// kernels_misc.hip -- the non-GEMM stages of the detect path on gfx950: preprocess, SPPF max-pools,
-// nearest-2x upsample (the Detect head lives in kernels_head.hip).  All HBM/LDS-bound byte and
-// element work: coalesced 16-byte accesses, no MFMA.
+// kernels_misc.hip -- the non-GEMM stages of the detect path on gfx950: stand-alone preprocess (parity entry
+// point / fp32 engine) and the SPPF max-pools.  (Upsample+Concat is fused into the consumer conv, the Detect
+// tail lives in kernels_head.hip, preprocess+stem in kernels_stem.hip.)  HBM/LDS-bound element work:
+// 16-byte accesses, no MFMA.
 #include "zly_internal.h"
 
 namespace zly {
@@ -175,46 +176,6 @@ hipError_t launch_sppf_pool(int dtype, void* buf, int cs, int c, int n, int H, i
     } else {
         if (lds > 64 * 1024) hipFuncSetAttribute((const void*)sppf_pool_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(sppf_pool_kernel<float>, grid, dim3(256), lds, s, (float*)buf, cs, c, H, W);
-    }
-    return hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------------------
-// nearest 2x upsample of a channel slice into a channel slice of the consumer's concat buffer
-// (nn.Upsample(scale_factor=2, mode="nearest") + Concat of yolov8.yaml layers 10-11, 13-14).
-// One thread moves 16 bytes (8 bf16 / 4 fp32 channels).
-// ------------------------------------------------------------------------------------------------
-template <typename T, int VEC>
-__global__ __launch_bounds__(256) void upsample2x_kernel(const T* __restrict__ in, int in_cs, int in_co,
-                                                         T* __restrict__ out, int out_cs, int out_co,
-                                                         int C, int H, int W, long total)
-{
-    typedef __attribute__((ext_vector_type(VEC))) T V;
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    const int cv = C / VEC;
-    const int chunk = (int)(i % cv);
-    long px = i / cv;                       // output pixel index over [n][2H][2W]
-    const int W2 = 2 * W, H2 = 2 * H;
-    const int x = (int)(px % W2); px /= W2;
-    const int y = (int)(px % H2);
-    const int f = (int)(px / H2);
-    const T* src = in + ((size_t)(f * H + (y >> 1)) * W + (x >> 1)) * in_cs + in_co + chunk * VEC;
-    T* dst = out + ((size_t)(f * H2 + y) * W2 + x) * out_cs + out_co + chunk * VEC;
-    *reinterpret_cast<V*>(dst) = *reinterpret_cast<const V*>(src);
-}
-
-hipError_t launch_upsample2x(int dtype, const void* in, int in_cs, int in_co, void* out, int out_cs, int out_co,
-                             int C, int n, int H, int W, hipStream_t s)
-{
-    if (dtype == ZLY_DTYPE_BF16) {
-        const long total = (long)n * 4 * H * W * (C / 8);
-        hipLaunchKernelGGL((upsample2x_kernel<bf16_t, 8>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
-                           (const bf16_t*)in, in_cs, in_co, (bf16_t*)out, out_cs, out_co, C, H, W, total);
-    } else {
-        const long total = (long)n * 4 * H * W * (C / 4);
-        hipLaunchKernelGGL((upsample2x_kernel<float, 4>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
-                           (const float*)in, in_cs, in_co, (float*)out, out_cs, out_co, C, H, W, total);
     }
     return hipGetLastError();
 }

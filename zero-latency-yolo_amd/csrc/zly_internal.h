@@ -52,8 +52,6 @@ hipError_t launch_preprocess(int dtype, const uint8_t* src, const FrameDesc* des
                              void* out_nhwc8, float* out_nchw_f32, int tw, int th, hipStream_t s);
 hipError_t launch_nchw_to_nhwc8(int dtype, const float* in_nchw, void* out_nhwc8, int n, int tw, int th, hipStream_t s);
 hipError_t launch_sppf_pool(int dtype, void* buf, int cs, int c, int n, int H, int W, hipStream_t s);
-hipError_t launch_upsample2x(int dtype, const void* in, int in_cs, int in_co, void* out, int out_cs, int out_co,
-                             int C, int n, int H, int W, hipStream_t s);
 hipError_t launch_tap_to_nchw(int dtype, const void* in, int cs, int co, int C, int H, int W, int idx, float* out, hipStream_t s);
 
 // kernels_stem.hip -- preprocess fused into the stem conv (bf16, 16-channel stem)
