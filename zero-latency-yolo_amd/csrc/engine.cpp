@@ -167,7 +167,7 @@ struct PlanBuilder {
         op.ks = r0->k; op.stride = r0->stride; op.act = r0->act; op.out_f32 = out_f32 ? 1 : 0;
         std::vector<uint8_t> w;
         std::vector<float> b;
-        repack_conv(srcs, cin_total, kstep, e->dtype == ZLY_DTYPE_BF16, &w, &b, &op.cout, &op.cout_pad, &op.nk);
+        repack_conv(srcs, cin_total, kstep, e->dtype == ZLY_DTYPE_BF16, &w, &b, &op.cout, &op.cout_pad, &op.nk, true);
         if (out.C != op.cout || out.co % 4 != 0 || ob.C % 4 != 0 || out.co + out.C > ob.C) { err = "bad output view for " + names[0]; return false; }
         if (out_f32 != ob.f32) { err = "output dtype mismatch for " + names[0]; return false; }
         const int Ho = ob.H, Wo = ob.W;

@@ -61,6 +61,84 @@ __device__ __forceinline__ f32x4 load4(const bf16_t* p) {
     return o;
 }
 __device__ __forceinline__ f32x4 load4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+// 8 consecutive channels (two MFMA tiles of a pair): one 16-byte bf16 store / two 16-byte fp32 stores
+__device__ __forceinline__ void store8(bf16_t* p, f32x4 a, f32x4 b) {
+    bf16x8 o;
+    o[0] = (bf16_t)a[0]; o[1] = (bf16_t)a[1]; o[2] = (bf16_t)a[2]; o[3] = (bf16_t)a[3];
+    o[4] = (bf16_t)b[0]; o[5] = (bf16_t)b[1]; o[6] = (bf16_t)b[2]; o[7] = (bf16_t)b[3];
+    *reinterpret_cast<bf16x8*>(p) = o;
+}
+__device__ __forceinline__ void store8(float* p, f32x4 a, f32x4 b) { *reinterpret_cast<f32x4*>(p) = a; *reinterpret_cast<f32x4*>(p + 4) = b; }
+__device__ __forceinline__ void load8(const bf16_t* p, f32x4& a, f32x4& b) {
+    const bf16x8 i = *reinterpret_cast<const bf16x8*>(p);
+    a = f32x4{(float)i[0], (float)i[1], (float)i[2], (float)i[3]};
+    b = f32x4{(float)i[4], (float)i[5], (float)i[6], (float)i[7]};
+}
+__device__ __forceinline__ void load8(const float* p, f32x4& a, f32x4& b) { a = *reinterpret_cast<const f32x4*>(p); b = *reinterpret_cast<const f32x4*>(p + 4); }
+
+// Output-channel map of MFMA tile `tile` (global tile index), lane group kq: with the pair permutation of
+// weights.cpp (all tiles below `paired_tiles`) a lane holds channels g*32 + kq*8 + half*4 .. +3; otherwise
+// tile*16 + kq*4 .. +3.
+__device__ __forceinline__ int tile_channel(int tile, int kq, int paired_tiles) {
+    return tile < paired_tiles ? (tile >> 1) * 32 + kq * 8 + (tile & 1) * 4 : tile * 16 + kq * 4;
+}
+
+// Shared epilogue of the conv kernels: bias + SiLU + residual, then NHWC stores.  Tiles c, c+1 of a pair that
+// sit in the same wave are written with ONE 16-byte store per lane (8 consecutive channels); 8-byte-per-lane
+// stores made the epilogue as expensive as the whole MFMA loop (store-issue bound, tools/diag_lds.hip).
+// per-lane bias of the CT channel tiles starting at tile0, fetched ONCE per wave before the main loop: a global
+// load inside the epilogue put an exposed L2 round trip (~1-2k cycles under load) at the end of every tile
+template <int CT>
+__device__ __forceinline__ void load_bias(const ConvArgs& a, int tile0, int kq, f32x4 (&bias)[CT])
+{
+    const int ntiles = (a.Cout + 15) >> 4;
+    const int paired = (ntiles >> 1) << 1;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        const int ch = tile_channel(tile0 + c, kq, paired);
+        bias[c] = ch < a.Cout ? *reinterpret_cast<const f32x4*>(a.bias + ch) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+template <typename T, int CT>
+__device__ __forceinline__ void epilogue_px(const ConvArgs& a, f32x4 (&v)[CT], const f32x4 (&bias)[CT], int tile0, int kq, int m)
+{
+    const int ntiles = (a.Cout + 15) >> 4;
+    const int paired = (ntiles >> 1) << 1;
+    f32x4 o[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        f32x4 x = v[c] + bias[c];
+        if (a.act) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[r] = silu<T>(x[r]);
+        }
+        o[c] = x;
+    }
+    const bool even0 = (tile0 & 1) == 0;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        const int tile = tile0 + c;
+        const int ch = tile_channel(tile, kq, paired);
+        if (ch >= a.Cout) continue;
+        const bool pair_here = even0 && (c % 2 == 0) && (c + 1 < CT) && (tile + 1 < paired);
+        if (pair_here) {
+            f32x4 lo = o[c], hi = o[c + 1 < CT ? c + 1 : c];
+            if (a.res) {
+                f32x4 ra, rb;
+                load8(static_cast<const T*>(a.res) + (m * a.res_cs + a.res_co + ch), ra, rb);
+                lo += ra; hi += rb;
+            }
+            if (a.out_f32) store8(static_cast<float*>(a.out) + (m * a.out_cs + a.out_co + ch), lo, hi);
+            else           store8(static_cast<T*>(a.out) + (m * a.out_cs + a.out_co + ch), lo, hi);
+        } else if (!(even0 && (c % 2 == 1) && (tile < paired))) {      // second tile of a pair already written above
+            f32x4 x = o[c];
+            if (a.res) x += load4(static_cast<const T*>(a.res) + (m * a.res_cs + a.res_co + ch));
+            if (a.out_f32) store4(static_cast<float*>(a.out) + (m * a.out_cs + a.out_co + ch), x);
+            else           store4(static_cast<T*>(a.out) + (m * a.out_cs + a.out_co + ch), x);
+        }
+    }
+}
 
 // MODE 0: 1x1 conv.  MODE 1: 3x3, Cin % KSTEP == 0 (a k-step never straddles a tap; tap/ci advance
 // incrementally).  MODE 2: 3x3, any Cin % EPL == 0 (tap = k / Cin by reciprocal multiply).
@@ -171,6 +249,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
             for (int t = 0; t < PT; ++t) acc[c][t] = mma_step(wf[c], af[t], acc[c][t]);
     };
 
+    f32x4 biasr[CT];
+    load_bias<CT>(a, blockIdx.y * CT, kq, biasr);         // in flight during the k-loop
     F wfA[CT], afA[PT], wfB[CT], afB[PT];
     if (s_begin < s_end) load_step(s_begin, wfA, afA);
     for (int s = s_begin; s < s_end; s += 2) {
@@ -205,30 +285,56 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
                         acc[c][t][r] += red[((w * CT + c) * PT + t) * 256 + r * 64 + lane];
     }
 
-    // epilogue: lane holds channels ch..ch+3 of pixel m for every (c, t)
+    // epilogue (see epilogue_px): per pixel tile, all CT channel tiles of this lane at once
 #pragma unroll
-    for (int c = 0; c < CT; ++c) {
-        const int ch = (blockIdx.y * CT + c) * 16 + kq * 4;
-        if (ch >= a.Cout) continue;
-        const f32x4 bias = *reinterpret_cast<const f32x4*>(a.bias + ch);
+    for (int t = 0; t < PT; ++t) {
+        const int m = m_base + t * 16 + p;
+        if (m >= a.M) continue;
+        f32x4 v[CT];
 #pragma unroll
-        for (int t = 0; t < PT; ++t) {
-            const int m = m_base + t * 16 + p;
-            if (m >= a.M) continue;
-            f32x4 v = acc[c][t] + bias;
-            if (a.act) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = silu<T>(v[r]);
-            }
-            if (a.res) {
-                const T* rp = static_cast<const T*>(a.res) + (size_t)m * a.res_cs + a.res_co + ch;
-                v += load4(rp);
-            }
-            if (a.out_f32) store4(static_cast<float*>(a.out) + (size_t)m * a.out_cs + a.out_co + ch, v);
-            else           store4(static_cast<T*>(a.out) + (size_t)m * a.out_cs + a.out_co + ch, v);
-        }
+        for (int c = 0; c < CT; ++c) v[c] = acc[c][t];
+        epilogue_px<T, CT>(a, v, biasr, blockIdx.y * CT, kq, m);
     }
 }
+
+#ifndef ZLY_TAPS_DEPTH
+#define ZLY_TAPS_DEPTH 0
+#endif
+#if ZLY_TAPS_DEPTH > 0
+// experimental: fragment reads software-pipelined ZLY_TAPS_DEPTH taps ahead of their MFMAs
+template <int CT, int PT, int S, int PW, int PITCH>
+__device__ __forceinline__ void taps_mma(const unsigned char* lpatch, const unsigned char* lw, int lane, int row0, int p, int kq,
+                                         f32x4 (&acc)[CT][PT])
+{
+    constexpr int D = ZLY_TAPS_DEPTH;
+    bf16x8 wf[D + 1][CT], af[D + 1][PT];
+    const unsigned char* wl = lw + lane * 16;
+    const unsigned char* al = lpatch + ((row0 * S) * PW + p * S) * PITCH + kq * 16;
+    auto rd = [&](int t, bf16x8 (&w)[CT], bf16x8 (&x)[PT]) {
+        const int ky = t / 3, kx = t - ky * 3;
+#pragma unroll
+        for (int cc = 0; cc < CT; ++cc) w[cc] = *reinterpret_cast<const bf16x8*>(wl + (t * CT + cc) * 1024);
+#pragma unroll
+        for (int i = 0; i < PT; ++i) x[i] = *reinterpret_cast<const bf16x8*>(al + ((i * S + ky) * PW + kx) * PITCH);
+    };
+#pragma unroll
+    for (int t = 0; t < D; ++t) rd(t, wf[t], af[t]);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        if (t + D < 9) rd(t + D, wf[(t + D) % (D + 1)], af[(t + D) % (D + 1)]);
+#ifdef ZLY_TAPS_PIN
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+        for (int cc = 0; cc < CT; ++cc)
+#pragma unroll
+            for (int i = 0; i < PT; ++i) acc[cc][i] = mma_step(wf[t % (D + 1)][cc], af[t % (D + 1)][i], acc[cc][i]);
+#ifdef ZLY_TAPS_PIN
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
+}
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // 3x3 convolution, LDS-tiled (bf16, Cin % 32 == 0, pad 1, stride S): the throughput kernel.
@@ -327,8 +433,18 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(const ConvArgs a, int 
 #pragma unroll
         for (int t = 0; t < PT; ++t) acc[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    f32x4 biasr[CT];
+    load_bias<CT>(a, blockIdx.y * CT, kq, biasr);
+#ifdef ZLY_DIAG
+    unsigned long long dsum[6] = {0, 0, 0, 0, 0, 0}, ditems = 0, dT0 = 0, dT1 = 0;
+#define ZSTAMP(t) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define ZPHASE(k) do { ZSTAMP(dT1); dsum[k] += dT1 - dT0; dT0 = dT1; } while (0)
+#endif
     // 9 taps of one staged chunk; the epilogue runs after a tile's last chunk
     auto compute = [&](int tl, int c) {
+#if ZLY_TAPS_DEPTH > 0
+        taps_mma<CT, PT, S, PW, PITCH>(lpatch, lw, lane, wave * PT, p, kq, acc);
+#else
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int ky = t / 3, kx = t - ky * 3;
@@ -346,32 +462,24 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(const ConvArgs a, int 
 #pragma unroll
                 for (int i = 0; i < PT; ++i) acc[cc][i] = mma_step(wf[cc], af[i], acc[cc][i]);
         }
+#endif
+#ifdef ZLY_DIAG
+        ZPHASE(3);
+#endif
         if (c != nchunks - 1) return;
-        // epilogue for tile tl: lane holds channels ch..ch+3 of pixel (oy, ox)
+        // epilogue for tile tl (see epilogue_px)
         const int b = tl / tiles_per_img;
         const int r = tl - b * tiles_per_img;
         const int ty = r / tiles_x, tx = r - ty * tiles_x;
         const int ox = tx * G::TW + p;
 #pragma unroll
-        for (int cc = 0; cc < CT; ++cc) {
-            const int ch = (blockIdx.y * CT + cc) * 16 + kq * 4;
-            const bool chok = ch < a.Cout;
-            const f32x4 bias = chok ? *reinterpret_cast<const f32x4*>(a.bias + ch) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < PT; ++i) {
+            const int oy = ty * G::TH + wave * PT + i;
+            f32x4 v[CT];
 #pragma unroll
-            for (int i = 0; i < PT; ++i) {
-                const int oy = ty * G::TH + wave * PT + i;
-                f32x4 v = acc[cc][i] + bias;
-                acc[cc][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (!chok || oy >= a.Ho || ox >= a.Wo) continue;
-                const int m = (b * a.Ho + oy) * a.Wo + ox;          // element offsets fit 31 bits (checked by the engine)
-                if (a.act) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] = silu<bf16_t>(v[q]);
-                }
-                if (a.res) v += load4(static_cast<const bf16_t*>(a.res) + (m * a.res_cs + a.res_co + ch));
-                if (a.out_f32) store4(static_cast<float*>(a.out) + (m * a.out_cs + a.out_co + ch), v);
-                else           store4(static_cast<bf16_t*>(a.out) + (m * a.out_cs + a.out_co + ch), v);
-            }
+            for (int cc = 0; cc < CT; ++cc) { v[cc] = acc[cc][i]; acc[cc][i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            if (oy >= a.Ho || ox >= a.Wo) continue;
+            epilogue_px<bf16_t, CT>(a, v, biasr, blockIdx.y * CT, kq, (b * a.Ho + oy) * a.Wo + ox);
         }
     };
 
@@ -385,25 +493,57 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(const ConvArgs a, int 
     u32x4 rpA[NPU_T], rwA[NWU_T], rpB[NPU_T], rwB[NWU_T];
     stage_load(t0, c0, rpA, rwA);
     if (t1 < total_tiles) stage_load(t1, c1, rpB, rwB);
+#ifdef ZLY_DIAG
+    // diagnostic build only (tools/diag_lds.hip): per-wave cycle sums of the phases of an item, written to the
+    // buffer passed in a.in2 (unused by 3x3 convs): [store+wait, barrier, load issue, taps+epilogue, barrier, items]
+
+    const unsigned long long dstart = __builtin_amdgcn_s_memtime();
+    ZSTAMP(dT0);
+#else
+#define ZPHASE(k) do { } while (0)
+#endif
     while (true) {
         // ---- item (t0,c0) from set A ----
         stage_store(rpA, rwA);
+        ZPHASE(0);
         __syncthreads();
+        ZPHASE(1);
         if (t2 < total_tiles) stage_load(t2, c2, rpA, rwA);
+        ZPHASE(2);
         compute(t0, c0);
+        ZPHASE(5);
         __syncthreads();
+        ZPHASE(4);
+#ifdef ZLY_DIAG
+        ++ditems;
+#endif
         if (t1 >= total_tiles) break;
         // ---- item (t1,c1) from set B ----
         int t3 = t2, c3 = c2; advance(t3, c3);
         stage_store(rpB, rwB);
+        ZPHASE(0);
         __syncthreads();
+        ZPHASE(1);
         if (t3 < total_tiles) stage_load(t3, c3, rpB, rwB);
+        ZPHASE(2);
         compute(t1, c1);
+        ZPHASE(5);
         __syncthreads();
+        ZPHASE(4);
+#ifdef ZLY_DIAG
+        ++ditems;
+#endif
         if (t2 >= total_tiles) break;
         t0 = t2; c0 = c2; t1 = t3; c1 = c3;
         t2 = t1; c2 = c1; advance(t2, c2);
     }
+#ifdef ZLY_DIAG
+    if (lane == 0 && a.in2) {
+        unsigned long long* o = (unsigned long long*)a.in2 + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8;
+        for (int k = 0; k < 5; ++k) o[k] = dsum[k];
+        o[5] = ditems; o[6] = __builtin_amdgcn_s_memtime() - dstart; o[7] = dsum[5];
+    }
+#endif
 }
 
 typedef void (*conv_lds_fn)(const ConvArgs, int, int, int);

@@ -91,7 +91,8 @@ uint16_t f32_to_bf16_rne(float f)
 }
 
 void repack_conv(const std::vector<const ConvRec*>& srcs, int cin_store, int kstep, bool bf16,
-                 std::vector<uint8_t>* w_out, std::vector<float>* bias_out, int* cout_total, int* cout_pad, int* nk)
+                 std::vector<uint8_t>* w_out, std::vector<float>* bias_out, int* cout_total, int* cout_pad, int* nk,
+                 bool pair_rows)
 {
     const int ks = srcs[0]->k, cin = srcs[0]->cin;
     int ctot = 0;
@@ -108,7 +109,15 @@ void repack_conv(const std::vector<const ConvRec*>& srcs, int cin_store, int kst
         for (int co = 0; co < s->cout; ++co) {
             const int row = co_base + co;
             (*bias_out)[(size_t)row] = s->b[(size_t)co];
-            const int ct = row / 16, r = row % 16;
+            // which MFMA tile / tile row computes output channel `row`.  With pair_rows, channels are dealt to tile
+            // PAIRS so that MFMA lane group kq ends up with channels 8kq..8kq+3 of a 32-channel group in the even tile
+            // and 8kq+4..8kq+7 in the odd tile: 8 consecutive channels per lane = one 16-byte NHWC store.
+            int ct = row / 16, r = row % 16;
+            if (pair_rows && (row / 32) * 32 + 32 <= cpad) {
+                const int g = row / 32, w = row % 32;
+                ct = 2 * g + ((w % 8) / 4);
+                r = (w / 8) * 4 + (w % 4);
+            }
             for (int ky = 0; ky < ks; ++ky)
                 for (int kx = 0; kx < ks; ++kx)
                     for (int ci = 0; ci < cin; ++ci) {

@@ -29,9 +29,12 @@ uint16_t f32_to_bf16_rne(float f);
 // Concatenates `srcs` along cout and lays the result out as the conv kernel reads it:
 //   [cout_pad/16][nk][lane = (kk/epl)*16 + row][epl] with k = (ky*ks + kx)*cin_store + ci = step*kstep + kk,
 //   zero padded: every 1 KiB tile is stored in MFMA lane order.
+// pair_rows: output channels are dealt to MFMA tile pairs so that a lane holds 8 consecutive channels (the conv
+// kernels' 16-byte epilogue stores); the bias stays in channel order.
 // cin_store is the channel count of the activation tensor the conv reads (>= cin; the stem reads an
 // 8-channel tensor for its 3 input channels).  bf16 -> 2-byte elements, else fp32.
 void repack_conv(const std::vector<const ConvRec*>& srcs, int cin_store, int kstep, bool bf16,
-                 std::vector<uint8_t>* w_out, std::vector<float>* bias_out, int* cout_total, int* cout_pad, int* nk);
+                 std::vector<uint8_t>* w_out, std::vector<float>* bias_out, int* cout_total, int* cout_pad, int* nk,
+                 bool pair_rows = false);
 
 }  // namespace zly
