@@ -55,7 +55,13 @@ weights: $(OUT)/yolov8n_synth.zlyw
 $(OUT)/yolov8n_synth.zlyw: $(PKG)/tools/zly_model.py | $(OUT)
 	$(PY) $(PKG)/tools/zly_model.py --scale n -o $@
 
+# ---- diagnostic build of the LDS conv kernel with s_memtime stamps per phase (never linked into libzly.so) --------
+diag: $(OUT)/diag_lds
+
+$(OUT)/diag_lds: $(PKG)/tools/diag_lds.hip $(CSRC)/kernels_conv.hip $(CSRC)/zly_internal.h | $(OUT)
+	$(HIPCC) $(HIPFLAGS) -DZLY_DIAG=1 $< -o $@
+
 clean:
 	rm -rf $(OUT) oracle/_build
 
-.PHONY: all host oracle weights clean
+.PHONY: all host oracle weights diag clean

@@ -297,11 +297,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
     }
 }
 
+// Fragment reads of the tap loop are software-pipelined ZLY_TAPS_DEPTH taps ahead of the MFMAs that consume them
+// (statically indexed fragment sets) and pinned with sched_barrier.  Left to itself hipcc issues each tap's
+// ds_reads 1-2 instructions before its MFMAs with lgkmcnt(0/1) waits in between.  Measured with the stamped
+// build (tools/diag_lds.hip): tap phase 2100 -> 1700 cycles per item at depth 1; depth 2 costs VGPRs (occupancy)
+// for no further gain; 0 = compiler schedule.
 #ifndef ZLY_TAPS_DEPTH
-#define ZLY_TAPS_DEPTH 0
+#define ZLY_TAPS_DEPTH 1
+#endif
+#ifndef ZLY_TAPS_PIN
+#define ZLY_TAPS_PIN 1
 #endif
 #if ZLY_TAPS_DEPTH > 0
-// experimental: fragment reads software-pipelined ZLY_TAPS_DEPTH taps ahead of their MFMAs
 template <int CT, int PT, int S, int PW, int PITCH>
 __device__ __forceinline__ void taps_mma(const unsigned char* lpatch, const unsigned char* lw, int lane, int row0, int p, int kq,
                                          f32x4 (&acc)[CT][PT])
@@ -322,14 +329,14 @@ __device__ __forceinline__ void taps_mma(const unsigned char* lpatch, const unsi
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         if (t + D < 9) rd(t + D, wf[(t + D) % (D + 1)], af[(t + D) % (D + 1)]);
-#ifdef ZLY_TAPS_PIN
+#if ZLY_TAPS_PIN
         __builtin_amdgcn_sched_barrier(0);
 #endif
 #pragma unroll
         for (int cc = 0; cc < CT; ++cc)
 #pragma unroll
             for (int i = 0; i < PT; ++i) acc[cc][i] = mma_step(wf[t % (D + 1)][cc], af[t % (D + 1)][i], acc[cc][i]);
-#ifdef ZLY_TAPS_PIN
+#if ZLY_TAPS_PIN
         __builtin_amdgcn_sched_barrier(0);
 #endif
     }
@@ -396,6 +403,10 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(const ConvArgs a, int 
         const int t = ti / CT, ct = ti - t * CT;
         uwsrc[i] = (ct * a.nk + t * nchunks) * 512 + l * 8;
     }
+    // Cin == 32: one chunk, so every item of this workgroup uses the SAME weight tiles: they are staged with the
+    // first item only (weights were 2/3 of the bytes staged per item; staging costs ~1/64 + 1/79 cycles per byte per CU)
+    const bool w_once = nchunks == 1;
+    bool w_staged = false;
     auto stage_load = [&](int tl, int c, u32x4 (&rp)[NPU_T], u32x4 (&rw)[NWU_T]) {
         const int b = tl / tiles_per_img;
         const int r = tl - b * tiles_per_img;
@@ -410,6 +421,7 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(const ConvArgs a, int 
                 v = *reinterpret_cast<const u32x4*>(inb + usrc[i]);
             rp[i] = v;
         }
+        if (w_once && tl != (int)blockIdx.x) return;          // only the workgroup's first item carries weights
         const bf16_t* wc = wbase + c * 512;
 #pragma unroll
         for (int i = 0; i < NWU_T; ++i) rw[i] = *reinterpret_cast<const u32x4*>(wc + uwsrc[i]);
@@ -420,6 +432,8 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(const ConvArgs a, int 
             const int u = tid + i * 256;
             if (u < NPU) *reinterpret_cast<u32x4*>(lpatch + (u >> 2) * PITCH + (u & 3) * 16) = rp[i];
         }
+        if (w_once && w_staged) return;
+        w_staged = true;
 #pragma unroll
         for (int i = 0; i < NWU_T; ++i) {
             const int u = tid + i * 256;
