@@ -57,7 +57,7 @@ struct GameState {
 // ---- common/result.h -----------------------------------------------------------------------------
 enum class ErrorCode {
     OK = 0, UNKNOWN_ERROR = 1, INVALID_ARGUMENT = 2, NOT_INITIALIZED = 3, TIMEOUT = 4,
-    NETWORK_ERROR = 100,
+    NETWORK_ERROR = 100, INVALID_PACKET = 103, PACKET_TOO_LARGE = 104, PROTOCOL_ERROR = 105,
     INFERENCE_ERROR = 200, MODEL_NOT_FOUND = 201, MODEL_LOAD_FAILED = 202, INVALID_INPUT = 203, INFERENCE_TIMEOUT = 204,
     SYSTEM_ERROR = 300, FILE_NOT_FOUND = 301, INSUFFICIENT_RESOURCES = 303,
     CONFIG_ERROR = 400

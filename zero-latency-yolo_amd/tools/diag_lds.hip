@@ -54,5 +54,8 @@ int main()
     run<1, 3, 2>("52x52 64->144 (x64) P3 stem", 64, 52, 52, 64, 144);
     run<1, 4, 2>("52x52 64->64 (x64) box2", 64, 52, 52, 64, 64);
     run<1, 2, 2>("52x52 32->32 (x64)", 64, 52, 52, 32, 32);
+    run<2, 4, 1>("104->52 s2 32->64 (x64)", 64, 104, 104, 32, 64);
+    run<2, 4, 1>("52->26 s2 64->128 (x64)", 64, 52, 52, 64, 128);
+    run<2, 4, 1>("26->13 s2 128->256 (x64)", 64, 26, 26, 128, 256);
     return 0;
 }
