@@ -34,7 +34,7 @@ $(OUT)/libzly.so: $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
 
 # ---- host side: the reference's IInferenceEngine plugin interface over the C ABI -----------------
-host: $(OUT)/libzly_plugin.so $(OUT)/test_hip_engine $(OUT)/test_wire
+host: $(OUT)/libzly_plugin.so $(OUT)/test_hip_engine $(OUT)/test_wire $(OUT)/test_game_step
 
 $(OUT)/libzly_plugin.so: $(HOST)/hip_inference_engine.cpp $(HOST)/hip_inference_engine.h $(HOST)/zly_compat.hpp include/zly.h $(OUT)/libzly.so
 	$(CXX) -O2 -std=c++17 -fPIC -shared -Iinclude -I$(HOST) -o $@ $(HOST)/hip_inference_engine.cpp -L$(OUT) -lzly -pthread -Wl,-rpath,'$$ORIGIN'
@@ -44,6 +44,9 @@ $(OUT)/test_hip_engine: tests/cpp/test_hip_engine.cpp $(OUT)/libzly_plugin.so
 
 $(OUT)/test_wire: tests/cpp/test_wire.cpp $(HOST)/zly_wire.hpp $(HOST)/zly_compat.hpp | $(OUT)
 	$(CXX) -O2 -std=c++17 -Wall -I$(HOST) -o $@ tests/cpp/test_wire.cpp
+
+$(OUT)/test_game_step: tests/cpp/test_game_step.cpp $(HOST)/zly_game_step.hpp $(HOST)/zly_compat.hpp | $(OUT)
+	$(CXX) -O2 -std=c++17 -Wall -I$(HOST) -o $@ tests/cpp/test_game_step.cpp
 
 # ---- CPU oracle (test infrastructure only) --------------------------------------------------------
 oracle: oracle/_build/libzly_oracle.so

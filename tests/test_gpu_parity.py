@@ -417,6 +417,38 @@ def test_yolov8s_widths(tmp_path, oracle):
     e.close()
 
 
+def test_four_class_cs16_head(tmp_path, oracle):
+    """The reference's CS 1.6 model has 4 classes (constants.h:35-40): head tensor [1, 8, N].  Class branch = one
+    16-row MFMA tile with 12 padded rows; decode and NMS must never see the padding."""
+    import yolov8_ref
+    spec = zm.build_spec("n", 4)
+    p = str(tmp_path / "yolov8n_cs16_synth.zlyw")
+    zm.write_zlyw(p, spec, zm.synth_weights(spec, seed=10))
+    ref = yolov8_ref.load(p, "fp32")
+    frames = zm.synth_frames(3, 416, 416, seed=13, rects=False)
+    x = _pre(oracle, frames, 416, 416)
+    want = ref.forward(torch.from_numpy(x)).numpy()
+    assert want.shape == (3, 8, 3549)
+    e = zly.Engine(p, dtype=zly.DTYPE_FP32, max_batch=3, max_dets=512, conf_thr=0.5, warmup_runs=0)
+    assert e.nc == 4
+    got = e.forward(x)
+    assert got.shape == want.shape
+    scale = max(1.0, float(np.abs(want[:, :4]).max()) / 800.0)
+    assert np.abs(got[:, :4] - want[:, :4]).max() <= 4 * FP32_BOX_TOL * scale
+    assert np.abs(got[:, 4:] - want[:, 4:]).max() <= 2 * FP32_SCORE_TOL
+    e.close()
+    e = zly.Engine(p, dtype=zly.DTYPE_BF16, max_batch=3, max_dets=512, conf_thr=0.5, warmup_runs=0)
+    total = 0
+    for f in frames:
+        dets, n = e.detect(f, cap=512)
+        own = oracle.postprocess(e.head_tensor(0), 416, 416, 0.5, 0.45)
+        assert n == len(own) and det_fields_equal(dets, own[:512])
+        assert n == 0 or (dets["class_id"][:min(n, 512)] < 4).all()
+        total += n
+    assert total > 0
+    e.close()
+
+
 def test_one_handle_from_several_host_threads(eng16):
     """The reference calls submitInference from the UDP thread while the monitor thread polls getStatus
     (SURVEY.md section 8b); one zly_engine handle must serialise concurrent callers and give each its own result."""
