@@ -12,16 +12,16 @@ HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -I$(CSRC) -Wal
 CXX      ?= g++
 PY       ?= python3
 
-KERNELS  := $(CSRC)/kernels_conv.hip $(CSRC)/kernels_misc.hip $(CSRC)/kernels_head.hip $(CSRC)/kernels_stem.hip $(CSRC)/kernels_post.hip
+KERNELS  := $(CSRC)/kernels_conv.hip $(CSRC)/kernels_pair.hip $(CSRC)/kernels_misc.hip $(CSRC)/kernels_head.hip $(CSRC)/kernels_stem.hip $(CSRC)/kernels_post.hip
 ENGINE   := $(CSRC)/engine.cpp $(CSRC)/weights.cpp
-OBJS     := $(OUT)/kernels_conv.o $(OUT)/kernels_misc.o $(OUT)/kernels_head.o $(OUT)/kernels_stem.o $(OUT)/kernels_post.o $(OUT)/engine.o $(OUT)/weights.o
+OBJS     := $(OUT)/kernels_conv.o $(OUT)/kernels_pair.o $(OUT)/kernels_misc.o $(OUT)/kernels_head.o $(OUT)/kernels_stem.o $(OUT)/kernels_post.o $(OUT)/engine.o $(OUT)/weights.o
 
 all: $(OUT)/libzly.so oracle weights host
 
 $(OUT):
 	mkdir -p $(OUT)
 
-$(OUT)/%.o: $(CSRC)/%.hip $(CSRC)/zly_internal.h include/zly.h | $(OUT)
+$(OUT)/%.o: $(CSRC)/%.hip $(CSRC)/zly_internal.h $(CSRC)/conv_device.h include/zly.h | $(OUT)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(OUT)/engine.o: $(CSRC)/engine.cpp $(CSRC)/zly_internal.h $(CSRC)/weights.h include/zly.h | $(OUT)

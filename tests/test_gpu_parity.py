@@ -160,7 +160,7 @@ def _assert_bf16_close(got, want):
     assert _rms(ds) <= BF16_SCORE_RMS and np.abs(ds).max() <= BF16_SCORE_MAX, (_rms(ds), np.abs(ds).max())
 
 
-def test_forward_bf16_vs_emulating_oracle(eng16, oracle, ref_bf16):
+def test_forward_bf16_vs_emulating_oracle(eng16, weights_path, oracle, ref_bf16):
     """bf16 engine vs the oracle that rounds at the same points.  The stem output (identical inputs)
     must agree to 1 bf16 ulp (2^-7 relative); the next layers -- one per conv kernel mode: 3x3 generic-K,
     1x1, 3x3 with residual, 3x3 fast-K -- to 2^-5 of the tensor's range, which pins the bf16 MFMA
@@ -168,6 +168,10 @@ def test_forward_bf16_vs_emulating_oracle(eng16, oracle, ref_bf16):
     frames = zm.synth_frames(2, 416, 416, seed=6, rects=False)
     x = _pre(oracle, frames)
     want = ref_bf16.forward(torch.from_numpy(x)).numpy()
+    got = eng16.forward(x)
+    _assert_bf16_close(got, want)
+    # per-layer taps from an engine that runs every conv as its own kernel (the fused bottleneck keeps m.0.cv1 in LDS)
+    eng16 = zly.Engine(weights_path, max_batch=2, warmup_runs=0, flags=zly.FLAG_NO_FUSION)
     got = eng16.forward(x)
     t, g = ref_bf16.taps["model.0"][1].numpy(), eng16.tap("model.0", 1)
     assert np.all(np.abs(g - t) <= 2.0 ** -7 * np.abs(t) + 1e-6)      # same inputs: at most 1 ulp apart
@@ -177,6 +181,7 @@ def test_forward_bf16_vs_emulating_oracle(eng16, oracle, ref_bf16):
         g = eng16.tap(name, 1)
         assert np.abs(g - t).max() <= 2.0 ** -5 * np.abs(t).max(), name
     _assert_bf16_close(got, want)
+    eng16.close()
 
 
 def test_forward_bf16_vs_fp32_oracle(eng16, oracle, ref_fp32):
@@ -414,6 +419,89 @@ def test_yolov8s_widths(tmp_path, oracle):
         dets, n = e.detect(f, cap=512)
         own = oracle.postprocess(e.head_tensor(0), 320, 320, 0.05, 0.45)
         assert n == len(own) and det_fields_equal(dets, own[:512])
+    e.close()
+
+
+def test_streaming_1x1_kernel(weights_path, oracle, monkeypatch):
+    """conv1x1_stream_kernel (persistent waves, next pixel group in flight, buffer addressing) against the one-shot 1x1
+    kernel: same MFMA order, so bit-identical wherever the one-shot launch does not split K (model.2.cv1 / cv2 with a
+    48-channel input / model.4.cv1); ZLY_STREAM_WGS=8 makes every wave loop over many groups, 52x52x3 pixels leave a
+    partial last group (hardware range check: reads 0, stores dropped).  Guards the gfx950 store hazard found here: a
+    16-byte buffer store with an SGPR soffset followed by a VALU write of its data registers stored garbage in dword 1."""
+    frames = zm.synth_frames(3, 416, 416, seed=5, rects=False)
+    x = _pre(oracle, frames)
+    monkeypatch.setenv("ZLY_NO_STREAM", "1")
+    a = zly.Engine(weights_path, max_batch=3, warmup_runs=0, flags=zly.FLAG_NO_FUSION)
+    ha = a.forward(x)
+    names = ("model.2.cv1", "model.2.cv2", "model.4.cv1")
+    ta = {k: [a.tap(k, i) for i in range(3)] for k in names}
+    a.close()
+    monkeypatch.delenv("ZLY_NO_STREAM")
+    monkeypatch.setenv("ZLY_STREAM_MIN_GROUPS", "1")
+    for wgs in ("8", "1024"):
+        monkeypatch.setenv("ZLY_STREAM_WGS", wgs)
+        b = zly.Engine(weights_path, max_batch=3, warmup_runs=0, flags=zly.FLAG_NO_FUSION)
+        hb = b.forward(x)
+        for k in names:
+            for i in range(3):
+                assert np.array_equal(b.tap(k, i), ta[k][i]), (wgs, k, i)
+        assert np.isfinite(hb).all()
+        _assert_bf16_close(hb, ha)
+        b.close()
+
+
+PAIR_TAPS = ("model.2.m.0.cv2", "model.4.m.0.cv2", "model.4.m.1.cv2", "model.15.m.0.cv2")
+
+
+@pytest.mark.parametrize("w,h,n", [(416, 416, 16), (320, 256, 2), (352, 288, 5)])
+def test_fused_bottleneck_pairs(weights_path, oracle, monkeypatch, w, h, n):
+    """kernels_pair.hip (3x3 -> 3x3 [+ shortcut] with the intermediate map in LDS) against the one-kernel-per-conv path
+    and the rounding-emulating oracle.  ZLY_PAIR_MIN_TILES=1 forces the fused kernel onto these small batches; the map
+    sizes cover tiles that divide the map (104, 52) and ragged ones (88x72, 44x36, 80x64, 40x32).
+    32-channel pairs accumulate in the order of the unfused kernels: bit-identical, all the way to the head tensor, when
+    the unfused launch does not split K across waves (batch 16 here; the small batches take the 4-way split-K kernel).
+    The 16-channel pair uses one MFMA per tap (the unfused kernel: one per two taps): fp32 sums can differ in the last
+    bit before the bf16 rounding, so it is compared at its own output and against the oracle."""
+    import yolov8_ref
+    monkeypatch.setenv("ZLY_PAIR_MIN_TILES", "1")
+    frames = zm.synth_frames(n, w, h, seed=31, rects=False)
+    x = _pre(oracle, frames, w, h)
+    plain = zly.Engine(weights_path, model_w=w, model_h=h, max_batch=n, warmup_runs=0, flags=zly.FLAG_NO_FUSION)
+    hp = plain.forward(x)
+    tp = {name: [plain.tap(name, i) for i in range(n)] for name in PAIR_TAPS}
+    plain.close()
+
+    monkeypatch.setenv("ZLY_PAIR_WIDTHS", "32")
+    e = zly.Engine(weights_path, model_w=w, model_h=h, max_batch=n, warmup_runs=0)
+    h32 = e.forward(x)
+    with pytest.raises(zly.ZlyError):
+        e.tap("model.4.m.0.cv1", 0)                           # stays in LDS
+    e.tap("model.2.m.0.cv1", 0)                               # this width is not fused in this engine
+    for name in PAIR_TAPS[1:2] if n < 16 else PAIR_TAPS:          # small batches: first fused layer only (same input in both engines)
+        for i in range(n):
+            g = e.tap(name, i)
+            if n >= 16:
+                assert np.array_equal(g, tp[name][i]), (name, i, float(np.mean(g != tp[name][i])))
+            else:
+                assert np.abs(g - tp[name][i]).max() <= 2.0 ** -6 * np.abs(g).max() and np.mean(g != tp[name][i]) < 0.05, (name, i)
+    if n >= 16:
+        assert np.array_equal(h32, hp)
+    else:
+        _assert_bf16_close(h32, hp)
+    e.close()
+
+    monkeypatch.setenv("ZLY_PAIR_WIDTHS", "16")
+    e = zly.Engine(weights_path, model_w=w, model_h=h, max_batch=n, warmup_runs=0)
+    h16 = e.forward(x)
+    ref = yolov8_ref.load(weights_path, "bf16")
+    ref.forward(torch.from_numpy(x))
+    for i in range(n):
+        g, t = e.tap("model.2.m.0.cv2", i), ref.taps["model.2.m.0.cv2"][i].numpy()
+        rng = np.abs(t).max()
+        assert np.abs(g - tp["model.2.m.0.cv2"][i]).max() <= 2.0 ** -6 * rng
+        assert np.mean(g != tp["model.2.m.0.cv2"][i]) < 0.05
+        assert np.abs(g - t).max() <= 2.0 ** -5 * rng
+    _assert_bf16_close(h16, hp)
     e.close()
 
 

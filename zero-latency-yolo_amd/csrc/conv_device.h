@@ -1,0 +1,71 @@
+// conv_device.h -- device helpers shared by the MFMA convolution kernels (kernels_conv.hip, kernels_pair.hip):
+// fragment types, the MFMA step, the fused SiLU and the NHWC channel-group loads/stores.
+#pragma once
+#include "zly_internal.h"
+
+namespace zly {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+template <typename T> struct Frag;
+template <> struct Frag<bf16_t> { typedef bf16x8 type; static constexpr int EPL = 8; static constexpr int KSTEP = 32; };
+template <> struct Frag<float>  { typedef f32x4  type; static constexpr int EPL = 4; static constexpr int KSTEP = 16; };
+
+__device__ __forceinline__ f32x4 mma_step(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+// 16x16x4 f32: lane l supplies A[l&15][l>>4] and B[l>>4][l&15].  Element j of the 4 floats each lane
+// loaded is used by MFMA j, i.e. MFMA j sums k = {4q + j : q = 0..3}; both operands use the same
+// permutation, and over j = 0..3 every k of the 16-wide step is covered exactly once.
+__device__ __forceinline__ f32x4 mma_step(f32x4 a, f32x4 b, f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], c, 0, 0, 0);
+    return c;
+}
+
+template <typename T> __device__ __forceinline__ float silu(float v);
+template <> __device__ __forceinline__ float silu<float>(float v) { return v / (1.0f + expf(-v)); }
+// bf16 path: v_exp_f32 + v_rcp_f32 (1 ulp each), 5 VALU instead of the 16 of an IEEE divide; the result is
+// rounded to bf16 (8 bits) anyway.  The epilogue was the largest VALU consumer of the LDS kernel.
+template <> __device__ __forceinline__ float silu<bf16_t>(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.442695041f)); }
+
+__device__ __forceinline__ void store4(bf16_t* p, f32x4 v) {
+    bf16x4 o;
+    o[0] = (bf16_t)v[0]; o[1] = (bf16_t)v[1]; o[2] = (bf16_t)v[2]; o[3] = (bf16_t)v[3];
+    *reinterpret_cast<bf16x4*>(p) = o;
+}
+__device__ __forceinline__ void store4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ f32x4 load4(const bf16_t* p) {
+    bf16x4 i = *reinterpret_cast<const bf16x4*>(p);
+    f32x4 o = {(float)i[0], (float)i[1], (float)i[2], (float)i[3]};
+    return o;
+}
+__device__ __forceinline__ f32x4 load4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+// 8 consecutive channels (two MFMA tiles of a pair): one 16-byte bf16 store / two 16-byte fp32 stores
+__device__ __forceinline__ void store8(bf16_t* p, f32x4 a, f32x4 b) {
+    bf16x8 o;
+    o[0] = (bf16_t)a[0]; o[1] = (bf16_t)a[1]; o[2] = (bf16_t)a[2]; o[3] = (bf16_t)a[3];
+    o[4] = (bf16_t)b[0]; o[5] = (bf16_t)b[1]; o[6] = (bf16_t)b[2]; o[7] = (bf16_t)b[3];
+    *reinterpret_cast<bf16x8*>(p) = o;
+}
+__device__ __forceinline__ void store8(float* p, f32x4 a, f32x4 b) { *reinterpret_cast<f32x4*>(p) = a; *reinterpret_cast<f32x4*>(p + 4) = b; }
+__device__ __forceinline__ void load8(const bf16_t* p, f32x4& a, f32x4& b) {
+    const bf16x8 i = *reinterpret_cast<const bf16x8*>(p);
+    a = f32x4{(float)i[0], (float)i[1], (float)i[2], (float)i[3]};
+    b = f32x4{(float)i[4], (float)i[5], (float)i[6], (float)i[7]};
+}
+__device__ __forceinline__ void load8(const float* p, f32x4& a, f32x4& b) { a = *reinterpret_cast<const f32x4*>(p); b = *reinterpret_cast<const f32x4*>(p + 4); }
+
+// Output-channel map of MFMA tile `tile` (global tile index), lane group kq: with the pair permutation of
+// weights.cpp (all tiles below `paired_tiles`) a lane holds channels g*32 + kq*8 + half*4 .. +3; otherwise
+// tile*16 + kq*4 .. +3.
+__device__ __forceinline__ int tile_channel(int tile, int kq, int paired_tiles) {
+    return tile < paired_tiles ? (tile >> 1) * 32 + kq * 8 + (tile & 1) * 4 : tile * 16 + kq * 4;
+}
+
+}  // namespace zly

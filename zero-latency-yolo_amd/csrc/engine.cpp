@@ -62,6 +62,11 @@ struct Op {
     int c = 0;                         // sppf: hidden width; upsample: channels
     int level = 0, stride_px = 0, anchor_off = 0;
     int lane = 0;                      // 0 = main stream; 1, 2 = Detect-branch streams that run beside the neck
+    // fused bottleneck pair (kernels_pair.hip): pair = 1 on a bottleneck's first 3x3 conv (it then carries what the
+    // kernel needs of the second one), 2 on the second (a no-op when the pair kernel ran); 0 otherwise
+    int pair = 0, pair_c = 0, pair_res = 0;
+    View pair_out{-1, 0, 0};
+    size_t pair_wA = 0, pair_bA = 0, pair_wB = 0, pair_bB = 0;
     HeadArgs head{};                   // OP_HEAD: fused Detect tail
     double flops = 0, bytes = 0;
 };
@@ -107,6 +112,7 @@ struct zly_engine {
     hipStream_t side[2] = {nullptr, nullptr};     // P3 / P4 Detect branches (forked from and joined to the main stream)
     hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join[2] = {nullptr, nullptr};
     std::map<int, hipGraphExec_t> graphs;   // batch size -> captured forward+decode
+    std::map<long, std::pair<bool, PairPlan>> pair_plans;   // (c, n, H, W) -> fused bottleneck tile plan (or "run unfused")
     int last_n = 0;
 
     std::mutex mu;
@@ -203,6 +209,33 @@ struct PlanBuilder {
         *b_off = append(b.data(), b.size() * sizeof(float));
         return true;
     }
+    // The two convs just added are a bottleneck's 3x3 pair: when the fused kernel covers this width, the first op
+    // also carries the pair kernel's operands (for c = 16 its own weight tiling: one tap per 16x16x16 MFMA k-step).
+    bool mark_pair(const std::string& m, int c, bool shortcut) {
+        if (e->dtype != ZLY_DTYPE_BF16 || (c != 16 && c != 32) || e->ops.size() < 2) return true;
+        Op& B = e->ops[e->ops.size() - 1];
+        Op& A = e->ops[e->ops.size() - 2];
+        if (A.ks != 3 || B.ks != 3 || A.stride != 1 || B.stride != 1 || !A.act || !B.act || A.cout != c || B.cout != c) return true;
+        if (A.in.co % 8 || B.out.co % 8 || e->bufs[(size_t)A.in.buf].C % 8 || e->bufs[(size_t)B.out.buf].C % 8) return true;
+        A.pair = 1; B.pair = 2; A.pair_c = B.pair_c = c; A.pair_res = shortcut ? 1 : 0;
+        A.pair_out = B.out;
+        if (c == 32) { A.pair_wA = A.w_off; A.pair_bA = A.b_off; A.pair_wB = B.w_off; A.pair_bB = B.b_off; return true; }
+        const char* names[2] = {".cv1", ".cv2"};
+        size_t* wo[2] = {&A.pair_wA, &A.pair_wB};
+        size_t* bo[2] = {&A.pair_bA, &A.pair_bB};
+        for (int k = 0; k < 2; ++k) {
+            const ConvRec* r = e->model.find(m + names[k]);
+            if (!r) { err = "conv missing from model file: " + m + names[k]; return false; }
+            std::vector<uint8_t> w;
+            std::vector<float> b;
+            int cout = 0, cout_pad = 0, nk = 0;
+            repack_conv({r}, c, 16, true, &w, &b, &cout, &cout_pad, &nk, false, 4);
+            if (nk != 9 || cout_pad != 16) { err = "internal: pair weight tiling for " + m; return false; }
+            *wo[k] = append(w.data(), w.size());
+            *bo[k] = append(b.data(), b.size() * sizeof(float));
+        }
+        return true;
+    }
     // C2f(c1 -> c2, n bottlenecks): cv1 writes [0,2c) of the concat buffer, bottleneck i reads
     // [(1+i)c,(2+i)c) and writes [(2+i)c,(3+i)c), cv2 reads all (2+n)c channels.
     bool c2f(const std::string& p, View in, View out, int n, bool shortcut, int H, int W, View in2 = View{-1, 0, 0}) {
@@ -215,6 +248,7 @@ struct PlanBuilder {
             const int tmp = add_buffer(m + ".tmp", H, W, c);
             if (!conv({m + ".cv1"}, src, View{tmp, 0, c})) return false;
             if (!conv({m + ".cv2"}, View{tmp, 0, c}, View{cat, (2 + i) * c, c}, shortcut ? src : View{-1, 0, 0})) return false;
+            if (!mark_pair(m, c, shortcut)) return false;
         }
         return conv({p + ".cv2"}, View{cat, 0, (2 + n) * c}, out);
     }
@@ -393,6 +427,26 @@ static int build_plan(zly_engine* e, std::string* err)
 // ------------------------------------------------------------------------------------------------
 // execution
 // ------------------------------------------------------------------------------------------------
+// Fused bottleneck pair for this op at batch n?  Small launches (few tiles) stay on the per-conv kernels, which
+// split a layer into many more workgroups.  Same answer for both ops of a pair.
+static const PairPlan* pair_active(zly_engine* e, const Op& op, int n)
+{
+    if (!op.pair || e->dtype != ZLY_DTYPE_BF16 || (e->cfg.flags & ZLY_FLAG_NO_FUSION)) return nullptr;
+    const Buffer& b = e->bufs[(size_t)(op.pair == 1 ? op.in.buf : op.out.buf)];
+    const long key = (((long)op.pair_c * 4096 + n) * 4096 + b.H) * 4096 + b.W;
+    auto it = e->pair_plans.find(key);
+    if (it == e->pair_plans.end()) {
+        PairPlan pl{};
+        const char* mt = getenv("ZLY_PAIR_MIN_TILES");                 // tuning / tests: force the fused kernel onto small launches
+        const int min_tiles = mt ? atoi(mt) : 192;
+        const char* pw = getenv("ZLY_PAIR_WIDTHS");                   // bit mask of fused widths (16 | 32), default both
+        const int widths = pw ? atoi(pw) : 48;
+        const bool ok = (widths & op.pair_c) && pair_plan(op.pair_c, n, b.H, b.W, &pl) && pl.total_tiles >= min_tiles;
+        it = e->pair_plans.emplace(key, std::make_pair(ok, pl)).first;
+    }
+    return it->second.first ? &it->second.second : nullptr;
+}
+
 static hipError_t run_op(zly_engine* e, const Op& op, int n, const uint8_t* d_src, void* d_slabs_out, uint32_t tag0, hipStream_t s)
 {
     switch (op.kind) {
@@ -401,6 +455,22 @@ static hipError_t run_op(zly_engine* e, const Op& op, int n, const uint8_t* d_sr
     case OP_CONV: {
         const Buffer& ib = e->bufs[(size_t)op.in.buf];
         const Buffer& ob = e->bufs[(size_t)op.out.buf];
+        if (op.pair) {
+            const PairPlan* pl = pair_active(e, op, n);
+            if (pl && op.pair == 2) return hipSuccess;             // computed by the pair kernel launched at the first conv
+            if (pl) {
+                const Buffer& pb = e->bufs[(size_t)op.pair_out.buf];
+                PairArgs pa;
+                pa.in = ib.ptr; pa.in_cs = ib.C; pa.in_co = op.in.co;
+                pa.out = pb.ptr; pa.out_cs = pb.C; pa.out_co = op.pair_out.co;
+                pa.wA = (const char*)e->d_weights + op.pair_wA; pa.bA = (const float*)((const char*)e->d_weights + op.pair_bA);
+                pa.wB = (const char*)e->d_weights + op.pair_wB; pa.bB = (const float*)((const char*)e->d_weights + op.pair_bB);
+                pa.H = ib.H; pa.W = ib.W; pa.n = n;
+                pa.TH = pl->th; pa.TW = pl->tw; pa.tiles_x = pl->tiles_x; pa.tiles_y = pl->tiles_y; pa.total_tiles = pl->total_tiles;
+                pa.res = op.pair_res;
+                return launch_pair(op.pair_c, pa, *pl, s);
+            }
+        }
         ConvArgs a;
         a.in = ib.ptr; a.in_cs = ib.C; a.in_co = op.in.co;
         a.H = ib.H; a.W = ib.W; a.Cin = op.in.C;
@@ -419,7 +489,8 @@ static hipError_t run_op(zly_engine* e, const Op& op, int n, const uint8_t* d_sr
             a.H = ob.H; a.W = ob.W; a.Cin = op.in.C + op.in2.C;        // logical (full-size, concatenated) input
         }
         ConvLaunch cfg;
-        conv_pick_config(e->dtype, op.ks, op.stride, a.Cin, op.cout_pad, n, ob.H, ob.W, &cfg);
+        conv_pick_config(e->dtype, op.ks, op.stride, a.Cin, op.cout_pad, n, ob.H, ob.W, &cfg,
+                         a.in2 == nullptr && a.res == nullptr && a.act && !a.out_f32 && a.Cout % 32 == 0);
         return launch_conv(e->dtype, a, cfg, s);
     }
     case OP_SPPF: {
@@ -619,6 +690,7 @@ int32_t zly_create(const zly_config* cfg, zly_engine** out)
     if (cfg->device < 0 || cfg->device >= ndev) return fail(ZLY_ERR_INVALID_ARGUMENT, "device ordinal out of range");
     HIP_TRY(hipSetDevice(cfg->device), ZLY_ERR_SYSTEM);
     HIP_TRY(conv_init(), ZLY_ERR_SYSTEM);
+    HIP_TRY(pair_init(), ZLY_ERR_SYSTEM);
 
     zly_engine* e = new zly_engine();
     e->cfg = *cfg;
@@ -901,6 +973,8 @@ int32_t zly_debug_tap(zly_engine* e, const char* name, int32_t idx, float* out, 
         auto jt = e->tap_final.find(name);
         if (it != e->tap_index.end()) {
             const Op& op = e->ops[(size_t)it->second.first];
+            if (op.pair == 1 && e->last_n > 0 && pair_active(e, op, e->last_n))
+                return fail(ZLY_ERR_INVALID_ARGUMENT, std::string("tap ") + name + " stays in LDS inside the fused bottleneck kernel at this batch size; create the engine with ZLY_FLAG_NO_FUSION");
             buf = op.out.buf; co = op.out.co + op.tap_co[(size_t)it->second.second]; C = op.tap_c[(size_t)it->second.second];
             f32 = op.out_f32 != 0;
         } else if (jt != e->tap_final.end()) {

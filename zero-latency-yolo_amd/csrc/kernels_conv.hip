@@ -18,70 +18,9 @@
 // fp32 mode uses v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain) with a permuted k order inside each
 // 16-wide k-step so that both operands still arrive as 16-byte loads.
 #include "zly_internal.h"
+#include "conv_device.h"
 
 namespace zly {
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-
-template <typename T> struct Frag;
-template <> struct Frag<bf16_t> { typedef bf16x8 type; static constexpr int EPL = 8; static constexpr int KSTEP = 32; };
-template <> struct Frag<float>  { typedef f32x4  type; static constexpr int EPL = 4; static constexpr int KSTEP = 16; };
-
-__device__ __forceinline__ f32x4 mma_step(bf16x8 a, bf16x8 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-}
-// 16x16x4 f32: lane l supplies A[l&15][l>>4] and B[l>>4][l&15].  Element j of the 4 floats each lane
-// loaded is used by MFMA j, i.e. MFMA j sums k = {4q + j : q = 0..3}; both operands use the same
-// permutation, and over j = 0..3 every k of the 16-wide step is covered exactly once.
-__device__ __forceinline__ f32x4 mma_step(f32x4 a, f32x4 b, f32x4 c) {
-    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], c, 0, 0, 0);
-    return c;
-}
-
-template <typename T> __device__ __forceinline__ float silu(float v);
-template <> __device__ __forceinline__ float silu<float>(float v) { return v / (1.0f + expf(-v)); }
-// bf16 path: v_exp_f32 + v_rcp_f32 (1 ulp each), 5 VALU instead of the 16 of an IEEE divide; the result is
-// rounded to bf16 (8 bits) anyway.  The epilogue was the largest VALU consumer of the LDS kernel.
-template <> __device__ __forceinline__ float silu<bf16_t>(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.442695041f)); }
-
-__device__ __forceinline__ void store4(bf16_t* p, f32x4 v) {
-    bf16x4 o;
-    o[0] = (bf16_t)v[0]; o[1] = (bf16_t)v[1]; o[2] = (bf16_t)v[2]; o[3] = (bf16_t)v[3];
-    *reinterpret_cast<bf16x4*>(p) = o;
-}
-__device__ __forceinline__ void store4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
-__device__ __forceinline__ f32x4 load4(const bf16_t* p) {
-    bf16x4 i = *reinterpret_cast<const bf16x4*>(p);
-    f32x4 o = {(float)i[0], (float)i[1], (float)i[2], (float)i[3]};
-    return o;
-}
-__device__ __forceinline__ f32x4 load4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-// 8 consecutive channels (two MFMA tiles of a pair): one 16-byte bf16 store / two 16-byte fp32 stores
-__device__ __forceinline__ void store8(bf16_t* p, f32x4 a, f32x4 b) {
-    bf16x8 o;
-    o[0] = (bf16_t)a[0]; o[1] = (bf16_t)a[1]; o[2] = (bf16_t)a[2]; o[3] = (bf16_t)a[3];
-    o[4] = (bf16_t)b[0]; o[5] = (bf16_t)b[1]; o[6] = (bf16_t)b[2]; o[7] = (bf16_t)b[3];
-    *reinterpret_cast<bf16x8*>(p) = o;
-}
-__device__ __forceinline__ void store8(float* p, f32x4 a, f32x4 b) { *reinterpret_cast<f32x4*>(p) = a; *reinterpret_cast<f32x4*>(p + 4) = b; }
-__device__ __forceinline__ void load8(const bf16_t* p, f32x4& a, f32x4& b) {
-    const bf16x8 i = *reinterpret_cast<const bf16x8*>(p);
-    a = f32x4{(float)i[0], (float)i[1], (float)i[2], (float)i[3]};
-    b = f32x4{(float)i[4], (float)i[5], (float)i[6], (float)i[7]};
-}
-__device__ __forceinline__ void load8(const float* p, f32x4& a, f32x4& b) { a = *reinterpret_cast<const f32x4*>(p); b = *reinterpret_cast<const f32x4*>(p + 4); }
-
-// Output-channel map of MFMA tile `tile` (global tile index), lane group kq: with the pair permutation of
-// weights.cpp (all tiles below `paired_tiles`) a lane holds channels g*32 + kq*8 + half*4 .. +3; otherwise
-// tile*16 + kq*4 .. +3.
-__device__ __forceinline__ int tile_channel(int tile, int kq, int paired_tiles) {
-    return tile < paired_tiles ? (tile >> 1) * 32 + kq * 8 + (tile & 1) * 4 : tile * 16 + kq * 4;
-}
 
 // Shared epilogue of the conv kernels: bias + SiLU + residual, then NHWC stores.  Tiles c, c+1 of a pair that
 // sit in the same wave are written with ONE 16-byte store per lane (8 consecutive channels); 8-byte-per-lane
@@ -185,6 +124,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
         const int m = m_base + t * 16 + p;
         mval[t] = m < a.M;
         const int mm = mval[t] ? m : 0;
+        if (MODE == 0 && !dual) {
+            // plain 1x1 (stride 1, no padding): input pixel = output pixel, no (b, y, x) split needed -- the three
+            // integer divisions per pixel tile were a quarter of a wave's instructions in these streaming launches
+            iy0[t] = 0; ix0[t] = 0; boff2[t] = 0;
+            boff[t] = mm * a.in_cs + a.in_co;
+            continue;
+        }
         const int ox = mm % a.Wo;
         const int r = mm / a.Wo;
         const int oy = r % a.Ho;
@@ -234,7 +180,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
 #pragma unroll
         for (int t = 0; t < PT; ++t) {
             const int iy = iy0[t] + ky, ix = ix0[t] + kx;
-            const bool ok = mval[t] && kval && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            const bool ok = MODE == 0 ? (mval[t] && kval) : (mval[t] && kval && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W);
             F z;
 #pragma unroll
             for (int j = 0; j < EPL; ++j) z[j] = (T)0.0f;
@@ -297,6 +243,120 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 1x1 convolution, streaming variant (bf16, stride 1, single source, Cin <= 32 * NK): the throughput kernel of the
+// pointwise layers.  These launches move 20-110 MB through a handful of MFMAs per pixel; with one pixel group per
+// wave (kernel above) every wave exposes a full HBM/MALL round trip before its first MFMA and the chip holds too few
+// bytes in flight.  Here a wave is persistent over pixel groups (PT x 16 pixels, all of K) and always has the NEXT
+// group's activation fragments in flight while it runs the MFMAs and the SiLU epilogue of the current one; the weight
+// fragments of its CT channel tiles (CT x NK <= 16) stay in registers for the whole launch; no index divisions.
+// ------------------------------------------------------------------------------------------------
+template <int CT, int PT, int NK>
+__global__ __launch_bounds__(256) void conv1x1_stream_kernel(const ConvArgs a, int ngroups)
+{
+    static_assert(CT % 2 == 0, "channel tiles are stored in pairs (8 consecutive channels per lane)");
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int p = lane & 15, kq = lane >> 4;
+    const int gstride = gridDim.x * 4;
+    int g = blockIdx.x * 4 + wave;
+    if (g >= ngroups) return;
+
+    // Buffer resources over the input view and the output view: addresses are (wave-uniform byte offset of the pixel
+    // group: SGPR) + (per-lane byte offset, computed once: VGPR) + immediate, out-of-range pixels of the last group read
+    // zeros and their stores are dropped by the hardware range check -- no per-group address or bounds VALU at all.
+    const bf16_t* inb = static_cast<const bf16_t*>(a.in) + a.in_co;
+    bf16_t* outb = static_cast<bf16_t*>(a.out) + a.out_co + blockIdx.y * (CT * 16);
+    const unsigned in_bytes = (unsigned)(((size_t)(a.M - 1) * a.in_cs + min(a.Cin, a.in_cs - a.in_co)) * 2);
+    const unsigned out_bytes = (unsigned)(((size_t)(a.M - 1) * a.out_cs + CT * 16) * 2);
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(inb), 0, in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(outb, 0, out_bytes, 0x00020000);
+    int vin[PT], vout[PT];
+#pragma unroll
+    for (int t = 0; t < PT; ++t) {
+        vin[t] = ((t * 16 + p) * a.in_cs + kq * 8) * 2;
+        vout[t] = ((t * 16 + p) * a.out_cs + kq * 8) * 2;
+    }
+    const int gin = PT * 16 * a.in_cs * 2, gout = PT * 16 * a.out_cs * 2;       // bytes per pixel group
+
+    bf16x8 w[CT][NK];
+    {
+        const bf16_t* __restrict__ wp = static_cast<const bf16_t*>(a.wgt) + (size_t)(blockIdx.y * CT) * a.nk * 512 + lane * 8;
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int s = 0; s < NK; ++s) w[c][s] = *reinterpret_cast<const bf16x8*>(wp + ((size_t)c * a.nk + s) * 512);
+    }
+    // pair-permuted channel tiles (weights.cpp): tile 2j holds channels j*32 + kq*8 .. +3, tile 2j+1 the next four
+    f32x4 biasr[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+        biasr[c] = *reinterpret_cast<const f32x4*>(a.bias + blockIdx.y * (CT * 16) + (c >> 1) * 32 + kq * 8 + (c & 1) * 4);
+
+    auto load_group = [&](int grp, u32x4 (&x)[PT][NK]) {
+        const int so = grp * gin;
+#pragma unroll
+        for (int t = 0; t < PT; ++t)
+#pragma unroll
+            for (int s = 0; s < NK; ++s) x[t][s] = __builtin_amdgcn_raw_buffer_load_b128(rin, vin[t] + s * 64, so, 0);
+    };
+    auto compute = [&](int grp, const u32x4 (&x)[PT][NK]) {
+        f32x4 acc[CT][PT];
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int t = 0; t < PT; ++t) acc[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < NK; ++s)
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int t = 0; t < PT; ++t) acc[c][t] = mma_step(w[c][s], __builtin_bit_cast(bf16x8, x[t][s]), acc[c][t]);
+        const int so = grp * gout;
+#pragma unroll
+        for (int t = 0; t < PT; ++t)
+#pragma unroll
+            for (int c = 0; c < CT; c += 2) {
+                f32x4 lo = acc[c][t] + biasr[c], hi = acc[c + 1][t] + biasr[c + 1];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { lo[r] = silu<bf16_t>(lo[r]); hi[r] = silu<bf16_t>(hi[r]); }
+                bf16x8 o;
+                o[0] = (bf16_t)lo[0]; o[1] = (bf16_t)lo[1]; o[2] = (bf16_t)lo[2]; o[3] = (bf16_t)lo[3];
+                o[4] = (bf16_t)hi[0]; o[5] = (bf16_t)hi[1]; o[6] = (bf16_t)hi[2]; o[7] = (bf16_t)hi[3];
+                // the group offset goes into the VGPR offset, not soffset: with an SGPR soffset hipcc emits no wait state
+                // between a 16-byte buffer store and the next VALU write of its data registers (LLVM's hazard rule
+                // exempts that form), and on gfx950 lanes 12-15 of dword 1 were then stored from the overwritten register
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rout, vout[t] + so + (c >> 1) * 64, 0, 0);
+            }
+    };
+
+    u32x4 xA[PT][NK], xB[PT][NK];
+    load_group(g, xA);
+    while (true) {
+        const int g1 = g + gstride;
+        if (g1 < ngroups) load_group(g1, xB);
+        compute(g, xA);
+        if (g1 >= ngroups) break;
+        const int g2 = g1 + gstride;
+        if (g2 < ngroups) load_group(g2, xA);
+        compute(g1, xB);
+        if (g2 >= ngroups) break;
+        g = g2;
+    }
+}
+
+typedef void (*conv_stream_fn)(const ConvArgs, int);
+// (CT, PT, NK) shapes built: CT x NK <= 16 weight fragments, PT x NK <= 8 activation fragments per buffer
+static conv_stream_fn pick_stream(int ct, int pt, int nk)
+{
+#define ZLY_STREAM_CASE(C_, P_, N_) if (ct == C_ && pt == P_ && nk == N_) return conv1x1_stream_kernel<C_, P_, N_>
+    ZLY_STREAM_CASE(2, 4, 1); ZLY_STREAM_CASE(2, 4, 2);
+    ZLY_STREAM_CASE(4, 2, 1); ZLY_STREAM_CASE(4, 2, 2); ZLY_STREAM_CASE(4, 2, 3); ZLY_STREAM_CASE(4, 2, 4);
+    ZLY_STREAM_CASE(2, 1, 6); ZLY_STREAM_CASE(2, 1, 8);
+#undef ZLY_STREAM_CASE
+    return nullptr;
+}
+
 // Fragment reads of the tap loop are software-pipelined ZLY_TAPS_DEPTH taps ahead of the MFMAs that consume them
 // (statically indexed fragment sets) and pinned with sched_barrier.  Left to itself hipcc issues each tap's
 // ds_reads 1-2 instructions before its MFMAs with lgkmcnt(0/1) waits in between.  Measured with the stamped
@@ -357,7 +417,6 @@ __device__ __forceinline__ void taps_mma(const unsigned char* lpatch, const unsi
 // registers before the MFMAs of item i and written to LDS after them (one LDS buffer, so two
 // workgroups fit per CU and cover each other's barriers).
 // ------------------------------------------------------------------------------------------------
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 template <int S, int PT> struct LdsGeom {
     static constexpr int TH = 4 * PT, TW = 16;
@@ -652,10 +711,28 @@ static bool pick_lds_config(int stride, int cin, int cout_pad, int n, int Ho, in
     return true;
 }
 
-void conv_pick_config(int dtype, int ks, int stride, int cin, int cout_pad, int n, int Ho, int Wo, ConvLaunch* cfg)
+// streaming 1x1 kernel: single-source pointwise convs with enough pixels to keep persistent waves busy
+static bool pick_stream_config(int cin, int cout_pad, int M, ConvLaunch* cfg)
+{
+    const int nk = (cin + 31) / 32;
+    const int ntiles = cout_pad / 16;
+    int ct = 0, pt = 0;
+    if (nk <= 2 && ntiles == 2) { ct = 2; pt = 4; }
+    else if (nk <= 4 && ntiles % 4 == 0) { ct = 4; pt = 2; }
+    else if ((nk == 6 || nk == 8) && ntiles % 2 == 0) { ct = 2; pt = 1; }
+    if (!ct || !pick_stream(ct, pt, nk)) return false;
+    const char* mg = getenv("ZLY_STREAM_MIN_GROUPS");                     // tuning / tests: force the streaming kernel onto small launches
+    if ((long)M / (16 * pt) * (ntiles / ct) < (mg ? atol(mg) : 4096)) return false;   // too few pixel groups to keep persistent waves busy
+    cfg->stream = 1; cfg->ct = ct; cfg->pt = pt; cfg->ksplit = 1; cfg->fastk = 0; cfg->lds = 0;
+    return true;
+}
+
+void conv_pick_config(int dtype, int ks, int stride, int cin, int cout_pad, int n, int Ho, int Wo, ConvLaunch* cfg, bool streamable)
 {
     const int M = n * Ho * Wo;
-    cfg->ks = ks; cfg->lds = 0;
+    cfg->ks = ks; cfg->lds = 0; cfg->stream = 0;
+    const bool no_stream = getenv("ZLY_NO_STREAM") != nullptr;             // tuning / tests
+    if (dtype == ZLY_DTYPE_BF16 && ks == 1 && stride == 1 && streamable && !no_stream && pick_stream_config(cin, cout_pad, M, cfg)) return;
     if (dtype == ZLY_DTYPE_BF16 && ks == 3 && pick_lds_config(stride, cin, cout_pad, n, Ho, Wo, cfg)) return;
     conv_pick_direct(dtype, ks, cin, cout_pad, M, cfg);
 }
@@ -663,7 +740,7 @@ void conv_pick_config(int dtype, int ks, int stride, int cin, int cout_pad, int 
 void conv_pick_direct(int dtype, int ks, int cin, int cout_pad, int M, ConvLaunch* cfg)
 {
     const int kstep = conv_kstep(dtype);
-    cfg->ks = ks;
+    cfg->ks = ks; cfg->stream = 0;
     cfg->fastk = (ks == 3 && cin % kstep == 0) ? 1 : 0;
     cfg->ksplit = 1;
     const int ntiles = cout_pad / 16;
@@ -708,6 +785,22 @@ hipError_t launch_conv(int dtype, const ConvArgs& a, const ConvLaunch& cfg, hipS
         if (gx * ytiles > max_wgs) gx = max_wgs / ytiles;  // never more than are resident: a persistent workgroup
         if (gx > total) gx = total;                        // that has to wait for a slot runs a whole round alone
         hipLaunchKernelGGL(fn, dim3(gx, ytiles, 1), dim3(256), lds_bytes(a.stride, cfg.pt, cfg.ct), s, a, tiles_x, tiles_per_img, total);
+        return hipGetLastError();
+    }
+    if (cfg.ks == 1 && (a.stride != 1 || a.pad != 0)) return hipErrorInvalidValue;      // the 1x1 paths assume input pixel = output pixel
+    if (cfg.stream) {
+        const int nk = (a.Cin + 31) / 32;
+        conv_stream_fn sf = pick_stream(cfg.ct, cfg.pt, nk);
+        if (!sf || dtype != ZLY_DTYPE_BF16 || a.in2 || a.res || nk > a.nk || !a.act || a.out_f32 || a.Cout % 32 || a.in_cs % 8 || a.in_co % 8 || a.out_cs % 8 || a.out_co % 8)
+            return hipErrorInvalidValue;
+        const int cout_pad = (a.Cout + 15) / 16 * 16;
+        const int ytiles = cout_pad / (16 * cfg.ct);
+        const int ngroups = (a.M + 16 * cfg.pt - 1) / (16 * cfg.pt);
+        int gx = (ngroups + 3) / 4;
+        const char* sw = getenv("ZLY_STREAM_WGS");         // tuning / tests: total persistent workgroups (default ~4 per CU)
+        const int cap = (sw && atoi(sw) > 0 ? atoi(sw) : 1024) / ytiles > 0 ? (sw && atoi(sw) > 0 ? atoi(sw) : 1024) / ytiles : 1;
+        if (gx > cap) gx = cap;
+        hipLaunchKernelGGL(sf, dim3(gx, ytiles, 1), dim3(256), 0, s, a, ngroups);
         return hipGetLastError();
     }
     const int mode = cfg.ks == 1 ? 0 : (cfg.fastk ? 1 : 2);

@@ -1,0 +1,278 @@
+// kernels_pair.hip -- a C2f bottleneck (3x3 conv -> 3x3 conv [+ shortcut]) as ONE kernel, bf16, C = 16 or 32 channels.
+//
+// Replaces two conv nodes (+ the Add) that the reference executes inside Ort::Session::Run
+// (reference src/inference/onnx_engine.cpp:578-585): ultralytics Bottleneck = cv2(cv1(x)) (+ x), both 3x3, c -> c.
+//
+// These are the high-resolution layers of the net (104x104 x 16 ch, 52x52 x 32 ch at 416x416): a few MFMAs per pixel,
+// so run one at a time each launch is bound by writing its output to HBM and reading it back (and by one more
+// launch).  Here a workgroup owns a TH x TW output tile of one frame and keeps the intermediate map in LDS:
+//   stage   x patch  (TH+4) x (TW+4) x C   global -> registers (prefetched one tile ahead) -> LDS, zero outside the frame
+//   conv A  over the (TH+2) x (TW+2) halo region, bias + SiLU, ZERO outside the frame (conv B pads the intermediate
+//           map with zeros, not with conv A of the padded input), rounded to bf16 -> LDS          [same value the
+//           unfused path writes to HBM]
+//   conv B  over TH x TW from the LDS intermediate, bias + SiLU (+ x from the LDS patch) -> HBM, 16-byte stores
+// Both convs' weights (9 KB / 36 KB) are copied to LDS once per workgroup; workgroups are persistent over tiles.
+// Pixels of a region are linearised (q -> (q / RW, q % RW)) and cut into 16-pixel MFMA tiles, so a tile shape need
+// not be a multiple of 16 wide: 13 x 26, 26 x 26 ... are picked per layer on the host (pair_plan) to divide the map.
+// One workgroup per CU (up to 16 waves): phases are separated by workgroup barriers, and inside a phase waves sit at
+// different points of their (MFMA loop, SiLU epilogue) sequence, which overlaps the matrix and vector pipes.
+// C = 16 uses v_mfma_f32_16x16x16_bf16 (one tap = one k-step, 8-byte fragments, pixel pitch 48 B); C = 32 uses
+// v_mfma_f32_16x16x32_bf16 (16-byte fragments, pitch 96 B).  Pitches are conflict-free for the fragment reads
+// (tools/lds_pitch.py).
+#include "zly_internal.h"
+#include "conv_device.h"
+
+namespace zly {
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+
+template <int C> struct PairGeom;
+template <> struct PairGeom<16> {
+    static constexpr int CT = 1, FRAGB = 8, PITCH = 48, WTILE = 512;
+    typedef s16x4 frag;
+    static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0); }
+};
+template <> struct PairGeom<32> {
+    static constexpr int CT = 2, FRAGB = 16, PITCH = 96, WTILE = 1024;
+    typedef bf16x8 frag;
+    static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+
+__device__ __forceinline__ int div_small(int q, float inv) { return (int)(((float)q + 0.5f) * inv); }   // exact for q < 2^20, divisor < 2^10
+
+// 9 taps of one 16-pixel tile: src = LDS image with row pitch `rowb` bytes, `off` = this lane's pixel/k-group offset
+template <int C>
+__device__ __forceinline__ void pair_taps(const unsigned char* __restrict__ src, const unsigned char* __restrict__ lw, int off, int rowb, int lane,
+                                          f32x4 (&acc)[PairGeom<C>::CT])
+{
+    typedef PairGeom<C> G;
+    typedef typename G::frag F;
+#pragma unroll
+    for (int c = 0; c < G::CT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const unsigned char* wl = lw + lane * G::FRAGB;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const unsigned char* row = src + off + ky * rowb;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const F x = *reinterpret_cast<const F*>(row + kx * G::PITCH);
+#pragma unroll
+            for (int c = 0; c < G::CT; ++c) {
+                const F w = *reinterpret_cast<const F*>(wl + (c * 9 + ky * 3 + kx) * G::WTILE);
+                acc[c] = G::mma(w, x, acc[c]);
+            }
+        }
+    }
+}
+
+template <int C, int NW, int NLD>
+__global__ __launch_bounds__(NW * 64) void bottleneck_pair_kernel(const PairArgs a)
+{
+    typedef PairGeom<C> G;
+    constexpr int NT = NW * 64;
+    constexpr int UPP = C / 8;                        // 16-byte units per pixel
+    constexpr int WBYTES = 9 * G::CT * G::WTILE;      // one conv's weights
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* lwA = smem;
+    unsigned char* lwB = smem + WBYTES;
+    unsigned char* lin = smem + 2 * WBYTES;
+    const int PW = a.TW + 4, PH = a.TH + 4, MW = a.TW + 2, MH = a.TH + 2;
+    unsigned char* lmid = lin + (PH * PW * G::PITCH + 15) / 16 * 16;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p = lane & 15, kq = lane >> 4;
+    const bf16_t* __restrict__ in = static_cast<const bf16_t*>(a.in) + a.in_co;
+    bf16_t* __restrict__ out = static_cast<bf16_t*>(a.out) + a.out_co;
+
+    // weights of both convs -> LDS, once
+    for (int u = tid; u < 2 * WBYTES / 16; u += NT) {
+        const int which = u >= WBYTES / 16;
+        const int v = u - which * (WBYTES / 16);
+        *reinterpret_cast<u32x4_t*>(smem + (size_t)u * 16) = *reinterpret_cast<const u32x4_t*>(static_cast<const unsigned char*>(which ? a.wB : a.wA) + (size_t)v * 16);
+    }
+    // per-lane bias: C = 16 -> channels kq*4..+3; C = 32 (pair-permuted rows) -> tile 0: kq*8..+3, tile 1: kq*8+4..+7
+    f32x4 biasA[G::CT], biasB[G::CT];
+#pragma unroll
+    for (int c = 0; c < G::CT; ++c) {
+        const int ch = C == 16 ? kq * 4 : kq * 8 + c * 4;
+        biasA[c] = *reinterpret_cast<const f32x4*>(a.bA + ch);
+        biasB[c] = *reinterpret_cast<const f32x4*>(a.bB + ch);
+    }
+
+    const int NPU = PH * PW * UPP;                    // 16-byte units of the x patch (host guarantees NPU <= NT * NLD)
+    const float invPW = 1.0f / (float)PW, invMW = 1.0f / (float)MW, invTW = 1.0f / (float)a.TW;
+    const int tiles_per_img = a.tiles_x * a.tiles_y;
+    const int NPA = MH * MW, NPB = a.TH * a.TW;
+    const int ntA = (NPA + 15) >> 4, ntB = (NPB + 15) >> 4;
+
+    auto tile_origin = [&](int tl, int& b, int& y0, int& x0) {
+        b = tl / tiles_per_img;
+        const int r = tl - b * tiles_per_img;
+        const int ty = r / a.tiles_x;
+        y0 = ty * a.TH; x0 = (r - ty * a.tiles_x) * a.TW;
+    };
+    u32x4_t pre[NLD];
+    auto stage_load = [&](int tl) {
+        int b, y0, x0;
+        tile_origin(tl, b, y0, x0);
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int u = tid + i * NT;
+            u32x4_t v = {0u, 0u, 0u, 0u};
+            if (u < NPU) {
+                const int px = u / UPP, part = u - px * UPP;
+                const int py = div_small(px, invPW), pxx = px - py * PW;
+                const int gy = y0 - 2 + py, gx = x0 - 2 + pxx;
+                if ((unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W)
+                    v = *reinterpret_cast<const u32x4_t*>(in + ((size_t)(b * a.H + gy) * a.W + gx) * a.in_cs + part * 8);
+            }
+            pre[i] = v;
+        }
+    };
+    auto stage_store = [&]() {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int u = tid + i * NT;
+            if (u < NPU) {
+                const int px = u / UPP, part = u - px * UPP;
+                *reinterpret_cast<u32x4_t*>(lin + px * G::PITCH + part * 16) = pre[i];
+            }
+        }
+    };
+
+    int tl = blockIdx.x;
+    if (tl >= a.total_tiles) return;
+    stage_load(tl);
+    while (true) {
+        int b, y0, x0;
+        tile_origin(tl, b, y0, x0);
+        stage_store();
+        __syncthreads();                               // x patch (and, first time, the weights) visible; previous tile's readers done
+        const int tnext = tl + gridDim.x;
+        if (tnext < a.total_tiles) stage_load(tnext);
+
+        // ---- conv A: x patch -> intermediate map in LDS -------------------------------------------------------
+        for (int t = wave; t < ntA; t += NW) {
+            const int q = t * 16 + p;
+            const int qc = min(q, NPA - 1);
+            const int my = div_small(qc, invMW), mx = qc - my * MW;
+            f32x4 acc[G::CT];
+            pair_taps<C>(lin, lwA, (my * PW + mx) * G::PITCH + kq * G::FRAGB, PW * G::PITCH, lane, acc);
+            const int gy = y0 - 1 + my, gx = x0 - 1 + mx;
+            const bool inimg = (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+            f32x4 o[G::CT];
+#pragma unroll
+            for (int c = 0; c < G::CT; ++c) {
+                f32x4 v = acc[c] + biasA[c];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = inimg ? silu<bf16_t>(v[r]) : 0.0f;
+                o[c] = v;
+            }
+            if (q < NPA) {
+                unsigned char* dst = lmid + (my * MW + mx) * G::PITCH;
+                if (C == 16) store4(reinterpret_cast<bf16_t*>(dst) + kq * 4, o[0]);
+                else         store8(reinterpret_cast<bf16_t*>(dst) + kq * 8, o[0], o[G::CT - 1]);
+            }
+        }
+        __syncthreads();                               // intermediate map complete
+
+        // ---- conv B: intermediate -> output (+ shortcut from the x patch) --------------------------------------
+        for (int t = wave; t < ntB; t += NW) {
+            const int q = t * 16 + p;
+            const int qc = min(q, NPB - 1);
+            const int oy = div_small(qc, invTW), ox = qc - oy * a.TW;
+            f32x4 acc[G::CT];
+            pair_taps<C>(lmid, lwB, (oy * MW + ox) * G::PITCH + kq * G::FRAGB, MW * G::PITCH, lane, acc);
+            f32x4 o[G::CT];
+#pragma unroll
+            for (int c = 0; c < G::CT; ++c) {
+                f32x4 v = acc[c] + biasB[c];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = silu<bf16_t>(v[r]);
+                o[c] = v;
+            }
+            const int gy = y0 + oy, gx = x0 + ox;
+            if (q < NPB && gy < a.H && gx < a.W) {
+                const unsigned char* xs = lin + ((oy + 2) * PW + ox + 2) * G::PITCH;
+                bf16_t* dst = out + ((size_t)(b * a.H + gy) * a.W + gx) * a.out_cs;
+                if (C == 16) {
+                    if (a.res) o[0] += load4(reinterpret_cast<const bf16_t*>(xs) + kq * 4);
+                    store4(dst + kq * 4, o[0]);
+                } else {
+                    if (a.res) {
+                        f32x4 ra, rb;
+                        load8(reinterpret_cast<const bf16_t*>(xs) + kq * 8, ra, rb);
+                        o[0] += ra; o[G::CT - 1] += rb;
+                    }
+                    store8(dst + kq * 8, o[0], o[G::CT - 1]);
+                }
+            }
+        }
+        if (tnext >= a.total_tiles) break;
+        tl = tnext;
+        __syncthreads();                               // all reads of the x patch / intermediate done before they are overwritten
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+// waves per workgroup: c = 32 keeps a conv's 18 weight fragments in registers across its pixel-tile loop (the compiler hoists the
+// loop-invariant LDS reads), which needs the 256-VGPR budget of 2 waves per SIMD; c = 16 needs 18 registers for that and runs 16 waves
+static constexpr int PAIR_NW16 = 16, PAIR_NW32 = 8, PAIR_NLD = 4;
+static int pair_nw(int c) { return c == 16 ? PAIR_NW16 : PAIR_NW32; }
+static constexpr int PAIR_LDS_MAX = 160 * 1024;
+
+static int pair_pitch(int c) { return c == 16 ? PairGeom<16>::PITCH : PairGeom<32>::PITCH; }
+static int pair_wbytes(int c) { return c == 16 ? 9 * PairGeom<16>::WTILE : 9 * 2 * PairGeom<32>::WTILE; }
+static size_t pair_lds_bytes(int c, int th, int tw)
+{
+    const size_t pitch = (size_t)pair_pitch(c);
+    return 2 * (size_t)pair_wbytes(c) + ((size_t)(th + 4) * (tw + 4) * pitch + 15) / 16 * 16 + (size_t)(th + 2) * (tw + 2) * pitch;
+}
+
+// Tile shape for an H x W map and n frames: minimise (rounds of tiles over the 256 CUs) x (16-pixel tile rounds of the
+// two convs over the workgroup's waves + a fixed per-tile cost), subject to the LDS budget and the staging registers.
+bool pair_plan(int c, int n, int H, int W, PairPlan* plan)
+{
+    if (c != 16 && c != 32) return false;
+    const int ncu = 256, nw = pair_nw(c);
+    double best = 1e30;
+    for (int th = 4; th <= 32; ++th) {
+        for (int tw = 8; tw <= 64; ++tw) {
+            if (pair_lds_bytes(c, th, tw) > (size_t)PAIR_LDS_MAX) continue;
+            if ((th + 4) * (tw + 4) * (c / 8) > nw * 64 * PAIR_NLD) continue;
+            const int tx = (W + tw - 1) / tw, ty = (H + th - 1) / th;
+            const long tiles = (long)n * tx * ty;
+            const long rounds = (tiles + ncu - 1) / ncu;
+            const int ntA = ((th + 2) * (tw + 2) + 15) / 16, ntB = (th * tw + 15) / 16;
+            const double per_tile = (double)((ntA + nw - 1) / nw + (ntB + nw - 1) / nw) + 1.5 * 16 / nw;
+            const double cost = (double)rounds * per_tile;
+            if (cost < best) { best = cost; plan->th = th; plan->tw = tw; plan->tiles_x = tx; plan->tiles_y = ty; plan->total_tiles = (int)tiles; }
+        }
+    }
+    if (best >= 1e30) return false;
+    plan->grid = plan->total_tiles < ncu ? plan->total_tiles : ncu;
+    plan->lds_bytes = (int)pair_lds_bytes(c, plan->th, plan->tw);
+    return true;
+}
+
+hipError_t pair_init()
+{
+    hipError_t r = hipFuncSetAttribute((const void*)bottleneck_pair_kernel<16, PAIR_NW16, PAIR_NLD>, hipFuncAttributeMaxDynamicSharedMemorySize, PAIR_LDS_MAX);
+    if (r != hipSuccess) return r;
+    return hipFuncSetAttribute((const void*)bottleneck_pair_kernel<32, PAIR_NW32, PAIR_NLD>, hipFuncAttributeMaxDynamicSharedMemorySize, PAIR_LDS_MAX);
+}
+
+hipError_t launch_pair(int c, const PairArgs& a, const PairPlan& plan, hipStream_t s)
+{
+    if ((c != 16 && c != 32) || a.TH != plan.th || a.TW != plan.tw || plan.grid < 1) return hipErrorInvalidValue;
+    if (a.in_cs % 8 || a.in_co % 8 || a.out_cs % 8 || a.out_co % 8) return hipErrorInvalidValue;       // 16-byte channel groups
+    if (c == 16) hipLaunchKernelGGL((bottleneck_pair_kernel<16, PAIR_NW16, PAIR_NLD>), dim3((unsigned)plan.grid), dim3(PAIR_NW16 * 64), (size_t)plan.lds_bytes, s, a);
+    else         hipLaunchKernelGGL((bottleneck_pair_kernel<32, PAIR_NW32, PAIR_NLD>), dim3((unsigned)plan.grid), dim3(PAIR_NW32 * 64), (size_t)plan.lds_bytes, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace zly

@@ -92,7 +92,7 @@ uint16_t f32_to_bf16_rne(float f)
 
 void repack_conv(const std::vector<const ConvRec*>& srcs, int cin_store, int kstep, bool bf16,
                  std::vector<uint8_t>* w_out, std::vector<float>* bias_out, int* cout_total, int* cout_pad, int* nk,
-                 bool pair_rows)
+                 bool pair_rows, int epl_override)
 {
     const int ks = srcs[0]->k, cin = srcs[0]->cin;
     int ctot = 0;
@@ -101,7 +101,7 @@ void repack_conv(const std::vector<const ConvRec*>& srcs, int cin_store, int kst
     const int K = ks * ks * cin_store;
     const int nkk = (K + kstep - 1) / kstep;
     const size_t esz = bf16 ? 2 : 4;
-    const int epl = 16 / (int)esz;                 // elements per 16-byte fragment
+    const int epl = epl_override > 0 ? epl_override : 16 / (int)esz;   // k values one lane feeds per k-step (one 16-byte fragment by default)
     w_out->assign((size_t)cpad * nkk * kstep * esz, 0);
     bias_out->assign((size_t)cpad, 0.0f);
     int co_base = 0;

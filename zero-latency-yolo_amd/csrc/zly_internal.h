@@ -39,13 +39,29 @@ struct ConvArgs {
     const void* in2;  int in2_cs, in2_co, split_c;
 };
 
-struct ConvLaunch { int ks, ct, pt, fastk, ksplit, lds; };
+struct ConvLaunch { int ks, ct, pt, fastk, ksplit, lds, stream; };
 
 // kernels_conv.hip
 hipError_t launch_conv(int dtype, const ConvArgs& a, const ConvLaunch& cfg, hipStream_t s);
-void       conv_pick_config(int dtype, int ks, int stride, int cin, int cout_pad, int n, int Ho, int Wo, ConvLaunch* cfg);
+void       conv_pick_config(int dtype, int ks, int stride, int cin, int cout_pad, int n, int Ho, int Wo, ConvLaunch* cfg,
+                            bool streamable = false);   // streamable: single source, no residual, SiLU, bf16 output, Cout % 32 == 0
 hipError_t conv_init();
 int        conv_kstep(int dtype);
+
+// kernels_pair.hip -- a C2f bottleneck (two 3x3 convs, c -> c -> c, optional shortcut) as one kernel; bf16, c = 16 / 32
+struct PairArgs {
+    const void* in;  int in_cs, in_co;        // x (NHWC view); also the shortcut source
+    void* out;       int out_cs, out_co;
+    const void* wA;  const float* bA;         // first conv: weights tiled [c/16][9][lane][frag] (frag = 8 bf16, or 4 for c = 16)
+    const void* wB;  const float* bB;         // second conv
+    int H, W, n;
+    int TH, TW, tiles_x, tiles_y, total_tiles;
+    int res;                                  // 1 = add x to the output (after the activation)
+};
+struct PairPlan { int th, tw, tiles_x, tiles_y, total_tiles, grid, lds_bytes; };
+bool       pair_plan(int c, int n, int H, int W, PairPlan* plan);
+hipError_t pair_init();
+hipError_t launch_pair(int c, const PairArgs& a, const PairPlan& plan, hipStream_t s);
 
 // kernels_misc.hip
 hipError_t launch_preprocess(int dtype, const uint8_t* src, const FrameDesc* desc, int n,

@@ -26,6 +26,7 @@ ERR_SYSTEM = 300
 DTYPE_FP32, DTYPE_BF16 = 0, 1
 SLAB_OVERFLOW = 1
 FLAG_DUMP_LOGITS = 1
+FLAG_NO_FUSION = 2
 
 # every symbol include/zly.h declares (tests/test_abi.py checks the library exports them all)
 SYMBOLS = [
