@@ -426,7 +426,7 @@ template <int S, int PT> struct LdsGeom {
 };
 
 template <int S, int CT, int PT>
-__global__ __launch_bounds__(256) void conv3x3_lds_kernel(const ConvArgs a, int tiles_x, int tiles_per_img, int total_tiles)
+__global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const ConvArgs a, int tiles_x, int tiles_per_img, int total_tiles)
 {
     typedef LdsGeom<S, PT> G;
     constexpr int PW = G::PW, PITCH = G::PITCH;
@@ -571,6 +571,7 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(const ConvArgs a, int 
     // buffer passed in a.in2 (unused by 3x3 convs): [store+wait, barrier, load issue, taps+epilogue, barrier, items]
 
     const unsigned long long dstart = __builtin_amdgcn_s_memtime();
+    const unsigned long long drt0 = __builtin_amdgcn_s_memrealtime();        // constant 100 MHz: wall clock
     ZSTAMP(dT0);
 #else
 #define ZPHASE(k) do { } while (0)
@@ -612,7 +613,8 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(const ConvArgs a, int 
     }
 #ifdef ZLY_DIAG
     if (lane == 0 && a.in2) {
-        unsigned long long* o = (unsigned long long*)a.in2 + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8;
+        unsigned long long* o = (unsigned long long*)a.in2 + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 16;
+        o[8] = drt0; o[9] = __builtin_amdgcn_s_memrealtime();
         for (int k = 0; k < 5; ++k) o[k] = dsum[k];
         o[5] = ditems; o[6] = __builtin_amdgcn_s_memtime() - dstart; o[7] = dsum[5];
     }
