@@ -160,6 +160,7 @@ def run():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the batch-64 / latency / roofline legs")
     ap.add_argument("--eager", action="store_true", help="no hipGraph replay")
+    ap.add_argument("--keep-head", action="store_true", help="also materialise the fp32 [4+nc][N] head tensor (parity/debug output; the shipped plugin does not)")
     ap.add_argument("--dump-ops", default="", help="write the per-op hipEvent profile (name, ms, GFLOP, GB, TFLOP/s, GB/s) to this file")
     a = ap.parse_args()
 
@@ -183,7 +184,7 @@ def run():
     B = a.batch
     big = 64
     eng = zly.Engine(dtype=zly.DTYPE_BF16, max_batch=max(B, big), max_dets=64, device=local_rank, warmup_runs=3,
-                     use_graph=not a.eager)
+                     use_graph=not a.eager, flags=0 if a.keep_head else zly.FLAG_NO_HEAD_TENSOR)
     # a real (non-default) torch stream: the engine enqueues on it, and torch.distributed orders the RCCL
     # all-gather of the slabs behind it (with the legacy default stream the engine would fall back to its
     # own stream and the collective would not be ordered after NMS)

@@ -57,6 +57,8 @@ extern "C" {
 
 #define ZLY_FLAG_DUMP_LOGITS 1   /* also write the fp32 logits of the six final Detect convs (debug taps
                                    "model.22.cv2.L.2" / "model.22.cv3.L.2"); off in production */
+#define ZLY_FLAG_NO_HEAD_TENSOR 4 /* production: the Detect kernel decodes in registers and does not write the fp32 [4+nc][N] head tensor
+                                   (the reference's ORT output, 1.2 MB per frame); zly_head_tensor / zly_forward then return 2 */
 #define ZLY_FLAG_NO_FUSION   2   /* run every conv as its own kernel (no fused bottleneck pairs): every zly_debug_tap is then available */
 
 typedef struct zly_engine zly_engine;

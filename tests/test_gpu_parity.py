@@ -422,6 +422,23 @@ def test_yolov8s_widths(tmp_path, oracle):
     e.close()
 
 
+def test_production_flags_same_detections(weights_path):
+    """ZLY_FLAG_NO_HEAD_TENSOR (what the plugin and bench.py run): the Detect kernel skips the fp32 head tensor, the
+    detections are the same bytes; the parity entry points that need the tensor fail loudly."""
+    frames = zm.synth_frames(8, 416, 416, seed=41, rects=False)
+    a = zly.Engine(weights_path, max_batch=8, max_dets=128, conf_thr=0.25, warmup_runs=0)
+    b = zly.Engine(weights_path, max_batch=8, max_dets=128, conf_thr=0.25, warmup_runs=0, flags=zly.FLAG_NO_HEAD_TENSOR)
+    ra, rb = a.detect_batch(list(frames), cap=128), b.detect_batch(list(frames), cap=128)
+    assert sum(n for _, n in ra) > 0
+    for (da, na), (db, nb) in zip(ra, rb):
+        assert na == nb and det_fields_equal(da, db)
+    with pytest.raises(zly.ZlyError):
+        b.head_tensor(0)
+    with pytest.raises(zly.ZlyError):
+        b.forward(np.zeros((1, 3, 416, 416), np.float32))
+    a.close(); b.close()
+
+
 def test_streaming_1x1_kernel(weights_path, oracle, monkeypatch):
     """conv1x1_stream_kernel (persistent waves, next pixel group in flight, buffer addressing) against the one-shot 1x1
     kernel: same MFMA order, so bit-identical wherever the one-shot launch does not split K (model.2.cv1 / cv2 with a

@@ -499,7 +499,7 @@ static hipError_t run_op(zly_engine* e, const Op& op, int n, const uint8_t* d_sr
     }
     case OP_HEAD: {
         HeadArgs h = op.head;
-        h.head = e->d_head; h.desc = e->d_desc; h.conf_thr = e->cfg.conf_thr; h.cand = e->d_cand; h.cand_count = e->d_count;
+        h.head = (e->cfg.flags & ZLY_FLAG_NO_HEAD_TENSOR) ? nullptr : e->d_head; h.desc = e->d_desc; h.conf_thr = e->cfg.conf_thr; h.cand = e->d_cand; h.cand_count = e->d_count;
         return launch_head_fused(e->dtype, h, n, s);
     }
     case OP_NMS:
@@ -895,6 +895,7 @@ int32_t zly_forward(zly_engine* e, int32_t n, const float* images_nchw, float* h
     std::vector<size_t> offs((size_t)n, 0);
     rc = set_desc(e, n, ws.data(), hs.data(), offs.data(), e->stream);
     if (rc != ZLY_OK) return rc;
+    if (e->cfg.flags & ZLY_FLAG_NO_HEAD_TENSOR) return fail(ZLY_ERR_INVALID_ARGUMENT, "engine was created with ZLY_FLAG_NO_HEAD_TENSOR: the head tensor is not materialised");
     rc = run_path(e, n, nullptr, nullptr, 0, e->stream, false);
     if (rc != ZLY_OK) return rc;
     HIP_TRY(hipMemcpyAsync(head_out, e->d_head, (size_t)n * (4 + (size_t)e->nc) * e->N * sizeof(float), hipMemcpyDeviceToHost, e->stream), ZLY_ERR_INFERENCE);
@@ -908,6 +909,7 @@ int32_t zly_head_tensor(zly_engine* e, int32_t idx, float* head_out)
     if (!head_out || idx < 0 || idx >= e->cfg.max_batch) return fail(ZLY_ERR_INVALID_ARGUMENT, "bad argument");
     std::lock_guard<std::mutex> lk(e->mu);
     HIP_TRY(hipSetDevice(e->dev), ZLY_ERR_SYSTEM);
+    if (e->cfg.flags & ZLY_FLAG_NO_HEAD_TENSOR) return fail(ZLY_ERR_INVALID_ARGUMENT, "engine was created with ZLY_FLAG_NO_HEAD_TENSOR: the head tensor is not materialised");
     const size_t per = (4 + (size_t)e->nc) * e->N;
     HIP_TRY(hipMemcpyAsync(head_out, e->d_head + per * (size_t)idx, per * sizeof(float), hipMemcpyDeviceToHost, e->stream), ZLY_ERR_INFERENCE);
     HIP_TRY(hipStreamSynchronize(e->stream), ZLY_ERR_INFERENCE);

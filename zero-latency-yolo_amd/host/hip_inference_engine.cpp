@@ -64,6 +64,7 @@ Result<void> HipInferenceEngine::initialize()
         c.dtype = envInt("ZLY_FP32", 0) ? ZLY_DTYPE_FP32 : ZLY_DTYPE_BF16;
         c.warmup_runs = 3;                                   // onnx_engine.cpp:919-954
         c.use_graph = 1;
+        c.flags = ZLY_FLAG_NO_HEAD_TENSOR;                   // the server only consumes detections
         zly_engine* e = nullptr;
         const int32_t rc = zly_create(&c, &e);
         if (rc != ZLY_OK) {

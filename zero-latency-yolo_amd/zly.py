@@ -27,6 +27,7 @@ DTYPE_FP32, DTYPE_BF16 = 0, 1
 SLAB_OVERFLOW = 1
 FLAG_DUMP_LOGITS = 1
 FLAG_NO_FUSION = 2
+FLAG_NO_HEAD_TENSOR = 4
 
 # every symbol include/zly.h declares (tests/test_abi.py checks the library exports them all)
 SYMBOLS = [
