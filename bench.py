@@ -59,19 +59,29 @@ FORCE_GATHER = os.environ.get("ZLY_BENCH_FORCE_GATHER") == "1"
 
 
 def run_steps(eng, frame_sets, batch, steps, slabs, stream_ptr, world, gather_out):
-    """enqueue `steps` steps; with world > 1 all-gather each step's slabs, overlapped with the next."""
+    """enqueue `steps` steps.  The engine runs NMS of step k on its own stream beside the first kernels of step k+1
+    (ZLY_FLAG_ASYNC_NMS); with world > 1 the slabs of step k are all-gathered once step k+1 has been enqueued:
+    zly_join orders the stream behind NMS(k), then the collective is queued -- overlapped with step k+1."""
     import torch.distributed as dist
     works = []
+    gather = world > 1 or FORCE_GATHER
+
+    def gather_step(j, lag):
+        eng.join(stream_ptr, lag)
+        if len(works) >= 2:
+            works.pop(0).wait()                        # gather buffer j%2 is free again once its previous gather finished
+        works.append(dist.all_gather_into_tensor(gather_out[j % 2], slabs[j % 3], async_op=True))
+
     for k in range(steps):
         d = frame_sets[k % len(frame_sets)]
-        s = slabs[k % 2]
-        eng.detect_device(d.data_ptr(), batch, 416, 416, d_slabs_ptr=s.data_ptr(), tag0=k * batch, stream=stream_ptr)
-        if world > 1 or FORCE_GATHER:
-            if len(works) >= 2:
-                works.pop(0).wait()                    # slab buffer k%2 is free again once its gather finished
-            works.append(dist.all_gather_into_tensor(gather_out[k % 2], s, async_op=True))
+        eng.detect_device(d.data_ptr(), batch, 416, 416, d_slabs_ptr=slabs[k % 3].data_ptr(), tag0=k * batch, stream=stream_ptr)
+        if gather and k > 0:
+            gather_step(k - 1, 1)                      # NMS(k-1), not NMS(k): step k+1 must not queue behind NMS(k)
+    if gather and steps > 0:
+        gather_step(steps - 1, 0)
     for w in works:
         w.wait()
+    eng.join(stream_ptr)                               # the last NMS is ordered into the timed stream
 
 
 def timed(eng, frame_sets, batch, steps, warmup, slabs, stream_ptr, world, gather_out):
@@ -161,6 +171,7 @@ def run():
     ap.add_argument("--no-extras", action="store_true", help="skip the batch-64 / latency / roofline legs")
     ap.add_argument("--eager", action="store_true", help="no hipGraph replay")
     ap.add_argument("--keep-head", action="store_true", help="also materialise the fp32 [4+nc][N] head tensor (parity/debug output; the shipped plugin does not)")
+    ap.add_argument("--sync-nms", action="store_true", help="run NMS in stream order at the end of every step instead of beside the next step's first kernels")
     ap.add_argument("--dump-ops", default="", help="write the per-op hipEvent profile (name, ms, GFLOP, GB, TFLOP/s, GB/s) to this file")
     a = ap.parse_args()
 
@@ -184,7 +195,7 @@ def run():
     B = a.batch
     big = 64
     eng = zly.Engine(dtype=zly.DTYPE_BF16, max_batch=max(B, big), max_dets=64, device=local_rank, warmup_runs=3,
-                     use_graph=not a.eager, flags=0 if a.keep_head else zly.FLAG_NO_HEAD_TENSOR)
+                     use_graph=not a.eager, flags=(0 if a.keep_head else zly.FLAG_NO_HEAD_TENSOR) | (0 if a.sync_nms else zly.FLAG_ASYNC_NMS))
     # a real (non-default) torch stream: the engine enqueues on it, and torch.distributed orders the RCCL
     # all-gather of the slabs behind it (with the legacy default stream the engine would fall back to its
     # own stream and the collective would not be ordered after NMS)
@@ -199,7 +210,7 @@ def run():
     sb = eng.slab_bytes
 
     def slab_bufs(n):
-        return [torch.zeros(n * sb, dtype=torch.uint8, device="cuda") for _ in range(2)]
+        return [torch.zeros(n * sb, dtype=torch.uint8, device="cuda") for _ in range(3)]   # step k's slabs are gathered while k+1 runs and k+2 is enqueued
 
     def gather_bufs(n):
         return [torch.zeros(world * n * sb, dtype=torch.uint8, device="cuda") for _ in range(2)] if (world > 1 or force_gather) else None

@@ -59,6 +59,9 @@ extern "C" {
                                    "model.22.cv2.L.2" / "model.22.cv3.L.2"); off in production */
 #define ZLY_FLAG_NO_HEAD_TENSOR 4 /* production: the Detect kernel decodes in registers and does not write the fp32 [4+nc][N] head tensor
                                    (the reference's ORT output, 1.2 MB per frame); zly_head_tensor / zly_forward then return 2 */
+#define ZLY_FLAG_ASYNC_NMS   8   /* zly_detect_device only: NMS of a call runs on an engine-owned stream beside the first kernels of the
+                                   NEXT call (it is 64 latency-bound workgroups).  The slabs of a call are then complete after zly_join
+                                   (stream order) or zly_sync / zly_read_slabs (host), whichever comes first. */
 #define ZLY_FLAG_NO_FUSION   2   /* run every conv as its own kernel (no fused bottleneck pairs): every zly_debug_tap is then available */
 
 typedef struct zly_engine zly_engine;
@@ -143,6 +146,9 @@ int32_t zly_detect_device(zly_engine* e, int32_t n, const void* d_frames, int32_
 size_t  zly_slab_bytes(const zly_engine* e);
 int32_t zly_read_slabs(zly_engine* e, int32_t n, void* host_slabs);   /* syncs the engine stream */
 int32_t zly_sync(zly_engine* e);
+/* ZLY_FLAG_ASYNC_NMS: make `stream` (NULL = the engine's own) wait, on the device, for the NMS of every zly_detect_device
+ * call made so far except the last `lag` ones (lag = 1: consume call k-1's slabs right after enqueuing call k). */
+int32_t zly_join(zly_engine* e, void* stream, int32_t lag);
 
 /* --- stage-level entry points (parity tests) ------------------------------------------------- */
 /* preProcess: out_nchw is host fp32 [3][model_h][model_w]. */

@@ -439,6 +439,46 @@ def test_production_flags_same_detections(weights_path):
     a.close(); b.close()
 
 
+def test_deferred_nms_same_slabs(weights_path):
+    """ZLY_FLAG_ASYNC_NMS: NMS of call k runs on the engine's own stream beside call k+1.  Five calls with different
+    batches and slab buffers must give byte-identical slabs to the in-order engine; zly_join / zly_read_slabs /
+    zly_sync are the points where a call's slabs are complete."""
+    n = 8
+    sets = [zm.synth_frames(n, 416, 416, seed=50 + i, rects=False) for i in range(3)]
+    dev = [torch.from_numpy(x).cuda() for x in sets]
+    a = zly.Engine(weights_path, max_batch=n, max_dets=64, conf_thr=0.25, warmup_runs=1)
+    b = zly.Engine(weights_path, max_batch=n, max_dets=64, conf_thr=0.25, warmup_runs=1, flags=zly.FLAG_ASYNC_NMS)
+    sb = a.slab_bytes
+    want = []
+    for k in range(5):
+        a.detect_device(dev[k % 3].data_ptr(), n, 416, 416, tag0=100 * k)
+        want.append(a.read_slabs(n))
+    stream = torch.cuda.Stream()
+    bufs = [torch.zeros(n * sb, dtype=torch.uint8, device="cuda") for _ in range(5)]
+    torch.cuda.synchronize()
+    with torch.cuda.stream(stream):
+        for k in range(5):
+            b.detect_device(dev[k % 3].data_ptr(), n, 416, 416, d_slabs_ptr=bufs[k].data_ptr(), tag0=100 * k, stream=stream.cuda_stream)
+        b.join(stream.cuda_stream)
+    stream.synchronize()
+    total = 0
+    for k in range(5):
+        got = zly.parse_slabs(bufs[k].cpu().numpy(), n, b.max_dets)
+        for i in range(n):
+            assert got[i][0]["n_kept"] == want[k][i][0]["n_kept"] and got[i][0]["frame_tag"] == 100 * k + i
+            assert det_fields_equal(got[i][1], want[k][i][1])
+            total += int(got[i][0]["n_kept"])
+    assert total > 0
+    # the internal slab buffer + zly_read_slabs (joins by itself), then a synchronous-path call on the same engine
+    b.detect_device(dev[1].data_ptr(), n, 416, 416, tag0=7)
+    got = b.read_slabs(n)
+    assert all(det_fields_equal(got[i][1], want[1][i][1]) for i in range(n))
+    d1, n1 = b.detect(sets[2][3], cap=64)
+    d2, n2 = a.detect(sets[2][3], cap=64)
+    assert n1 == n2 and det_fields_equal(d1, d2)
+    a.close(); b.close()
+
+
 def test_streaming_1x1_kernel(weights_path, oracle, monkeypatch):
     """conv1x1_stream_kernel (persistent waves, next pixel group in flight, buffer addressing) against the one-shot 1x1
     kernel: same MFMA order, so bit-identical wherever the one-shot launch does not split K (model.2.cv1 / cv2 with a

@@ -95,6 +95,17 @@ struct zly_engine {
     Cand* d_cand = nullptr;           // [max_batch][N]
     Cand* d_scratch = nullptr;        // [max_batch][N]  (NMS spill when a frame has > 1024 candidates)
     int* d_count = nullptr;           // [max_batch]
+    // ZLY_FLAG_ASYNC_NMS: second candidate buffer + a stream of its own for NMS, so that NMS of call k (64 workgroups,
+    // latency-bound) runs beside the first kernels of call k+1 instead of idling the chip at the end of every step
+    Cand* d_cand_alt = nullptr;
+    int* d_count_alt = nullptr;
+    Cand* cur_cand = nullptr;         // buffers the Detect tail / NMS of the current call use
+    int* cur_count = nullptr;
+    hipStream_t nms_stream = nullptr;
+    hipEvent_t ev_head = nullptr, ev_nms[2] = {nullptr, nullptr};
+    int parity = 0;
+    bool nms_recorded[2] = {false, false};
+    int last_async = -1;              // parity of the last deferred NMS, -1 = none outstanding
     unsigned char* d_slabs = nullptr; // [max_batch][slab_bytes]
     FrameDesc* d_desc = nullptr;      // [max_batch]
     FrameDesc* h_desc = nullptr;      // pinned
@@ -499,11 +510,11 @@ static hipError_t run_op(zly_engine* e, const Op& op, int n, const uint8_t* d_sr
     }
     case OP_HEAD: {
         HeadArgs h = op.head;
-        h.head = (e->cfg.flags & ZLY_FLAG_NO_HEAD_TENSOR) ? nullptr : e->d_head; h.desc = e->d_desc; h.conf_thr = e->cfg.conf_thr; h.cand = e->d_cand; h.cand_count = e->d_count;
+        h.head = (e->cfg.flags & ZLY_FLAG_NO_HEAD_TENSOR) ? nullptr : e->d_head; h.desc = e->d_desc; h.conf_thr = e->cfg.conf_thr; h.cand = e->cur_cand; h.cand_count = e->cur_count;
         return launch_head_fused(e->dtype, h, n, s);
     }
     case OP_NMS:
-        return launch_nms(e->d_cand, e->d_count, e->N, n, e->cfg.iou_thr, e->nc, e->d_scratch,
+        return launch_nms(e->cur_cand, e->cur_count, e->N, n, e->cfg.iou_thr, e->nc, e->d_scratch,
                           d_slabs_out ? d_slabs_out : e->d_slabs, e->cfg.max_dets, tag0, s);
     }
     return hipErrorInvalidValue;
@@ -544,9 +555,34 @@ static hipError_t run_ops(zly_engine* e, size_t first, size_t last, int n, const
     return r;
 }
 
-static int run_path(zly_engine* e, int n, const uint8_t* d_src, void* d_slabs_out, uint32_t tag0, hipStream_t s, bool with_pre)
+// every stream that may hold an outstanding deferred NMS is joined into `s`
+// lag = 0: all of them; lag = 1: all but the most recent call's (so that the caller can consume call k-1's slabs on
+// `s` right after enqueuing call k without putting NMS(k) in front of call k+1).  NMS launches are serialised on one
+// stream, so waiting for a call's event covers every earlier call.
+static int join_nms(zly_engine* e, hipStream_t s, int lag = 0)
+{
+    if (e->last_async < 0 || lag >= 2) return ZLY_OK;    // nothing outstanding / already ordered: a deferred call waits for the NMS two calls back
+    const int p = lag == 0 ? e->last_async : e->last_async ^ 1;
+    if (e->nms_recorded[p]) HIP_TRY(hipStreamWaitEvent(s, e->ev_nms[p], 0), ZLY_ERR_INFERENCE);
+    return ZLY_OK;
+}
+
+static int run_path(zly_engine* e, int n, const uint8_t* d_src, void* d_slabs_out, uint32_t tag0, hipStream_t s, bool with_pre, bool defer_nms = false)
 {
     const size_t nops = e->ops.size();
+    defer_nms = defer_nms && e->nms_stream != nullptr;
+    int par = 0;
+    if (defer_nms) {
+        // this call's Detect tail fills candidate buffer `par`; the NMS that last read it (two calls back) must be done
+        par = e->parity;
+        if (e->nms_recorded[par]) HIP_TRY(hipStreamWaitEvent(s, e->ev_nms[par], 0), ZLY_ERR_INFERENCE);
+    } else if (e->last_async >= 0) {
+        int rcj = join_nms(e, s);                       // a synchronous-path call after deferred ones: plain stream order again
+        if (rcj != ZLY_OK) return rcj;
+        e->last_async = -1;
+    }
+    e->cur_cand = par ? e->d_cand_alt : e->d_cand;
+    e->cur_count = par ? e->d_count_alt : e->d_count;
     // ops[0] = preprocess, ops[1] = model.0.  On the detect paths of the bf16 engine both are ONE kernel
     // (kernels_stem.hip); zly_forward (caller-supplied fp32 images) keeps the generic model.0 conv.
     const bool fused = with_pre && e->stem_fused;
@@ -560,7 +596,7 @@ static int run_path(zly_engine* e, int n, const uint8_t* d_src, void* d_slabs_ou
         HIP_TRY(run_op(e, e->ops[0], n, d_src, nullptr, 0, s), ZLY_ERR_INFERENCE);
     }
     if (e->cfg.use_graph) {
-        const int key = n * 2 + (fused ? 1 : 0);
+        const int key = (n * 2 + (fused ? 1 : 0)) * 2 + par;     // the captured Detect tail holds the candidate buffer's address
         auto it = e->graphs.find(key);
         if (it == e->graphs.end()) {
             // capture on the engine's own stream, then replay on whichever stream the caller uses
@@ -579,7 +615,15 @@ static int run_path(zly_engine* e, int n, const uint8_t* d_src, void* d_slabs_ou
     } else {
         HIP_TRY(run_ops(e, first, nops - 1, n, nullptr, nullptr, 0, s), ZLY_ERR_INFERENCE);
     }
-    HIP_TRY(run_op(e, e->ops[nops - 1], n, nullptr, d_slabs_out, tag0, s), ZLY_ERR_INFERENCE);
+    if (defer_nms) {
+        HIP_TRY(hipEventRecord(e->ev_head, s), ZLY_ERR_INFERENCE);
+        HIP_TRY(hipStreamWaitEvent(e->nms_stream, e->ev_head, 0), ZLY_ERR_INFERENCE);
+        HIP_TRY(run_op(e, e->ops[nops - 1], n, nullptr, d_slabs_out, tag0, e->nms_stream), ZLY_ERR_INFERENCE);
+        HIP_TRY(hipEventRecord(e->ev_nms[par], e->nms_stream), ZLY_ERR_INFERENCE);
+        e->nms_recorded[par] = true; e->last_async = par; e->parity = par ^ 1;
+    } else {
+        HIP_TRY(run_op(e, e->ops[nops - 1], n, nullptr, d_slabs_out, tag0, s), ZLY_ERR_INFERENCE);
+    }
     e->last_n = n;
     return ZLY_OK;
 }
@@ -640,9 +684,10 @@ static void destroy_engine(zly_engine* e)
     hipSetDevice(e->dev);
     if (e->stream) hipStreamSynchronize(e->stream);
     for (int i = 0; i < 2; ++i) if (e->side[i]) hipStreamSynchronize(e->side[i]);
+    if (e->nms_stream) hipStreamSynchronize(e->nms_stream);
     for (auto& kv : e->graphs) hipGraphExecDestroy(kv.second);
     for (Buffer& b : e->bufs) if (b.ptr) hipFree(b.ptr);
-    void* dptrs[] = {e->d_weights, e->d_head, e->d_cand, e->d_scratch, e->d_count, e->d_slabs, e->d_desc, e->d_stage, e->d_scratch_f32};
+    void* dptrs[] = {e->d_weights, e->d_head, e->d_cand, e->d_cand_alt, e->d_count_alt, e->d_scratch, e->d_count, e->d_slabs, e->d_desc, e->d_stage, e->d_scratch_f32};
     for (void* p : dptrs) if (p) hipFree(p);
     if (e->h_desc) hipHostFree(e->h_desc);
     if (e->h_stage) hipHostFree(e->h_stage);
@@ -652,6 +697,9 @@ static void destroy_engine(zly_engine* e)
         if (e->ev_join[i]) hipEventDestroy(e->ev_join[i]);
         if (e->side[i]) hipStreamDestroy(e->side[i]);
     }
+    if (e->ev_head) hipEventDestroy(e->ev_head);
+    for (int i = 0; i < 2; ++i) if (e->ev_nms[i]) hipEventDestroy(e->ev_nms[i]);
+    if (e->nms_stream) hipStreamDestroy(e->nms_stream);
     if (e->stream) hipStreamDestroy(e->stream);
     delete e;
 }
@@ -726,6 +774,16 @@ int32_t zly_create(const zly_config* cfg, zly_engine** out)
     if (!ok) { destroy_engine(e); return fail(ZLY_ERR_SYSTEM, "device allocation failed"); }
     hipMemset(e->d_slabs, 0, B * slab_bytes_of(e));
     hipMemset(e->d_count, 0, B * sizeof(int));
+    e->cur_cand = e->d_cand; e->cur_count = e->d_count;
+    if (cfg->flags & ZLY_FLAG_ASYNC_NMS) {
+        bool aok = hipMalloc((void**)&e->d_cand_alt, B * N * sizeof(Cand)) == hipSuccess && hipMalloc((void**)&e->d_count_alt, B * sizeof(int)) == hipSuccess &&
+                   hipStreamCreateWithFlags(&e->nms_stream, hipStreamNonBlocking) == hipSuccess &&
+                   hipEventCreateWithFlags(&e->ev_head, hipEventDisableTiming) == hipSuccess &&
+                   hipEventCreateWithFlags(&e->ev_nms[0], hipEventDisableTiming) == hipSuccess &&
+                   hipEventCreateWithFlags(&e->ev_nms[1], hipEventDisableTiming) == hipSuccess;
+        if (!aok) { destroy_engine(e); return fail(ZLY_ERR_SYSTEM, "device allocation failed (deferred NMS)"); }
+        hipMemset(e->d_count_alt, 0, B * sizeof(int));
+    }
 
     // warmupModel analogue (onnx_engine.cpp:919-954): constant-128 frames of model size
     if (cfg->warmup_runs > 0) {
@@ -826,10 +884,19 @@ int32_t zly_detect_device(zly_engine* e, int32_t n, const void* d_frames, int32_
     for (int i = 0; i < n; ++i) offs[(size_t)i] = (size_t)i * (size_t)w * (size_t)h * 3u;
     int rc = set_desc(e, n, ws.data(), hs.data(), offs.data(), s);
     if (rc != ZLY_OK) return rc;
-    rc = run_path(e, n, (const uint8_t*)d_frames, d_slabs, frame_tag0, s, true);
+    rc = run_path(e, n, (const uint8_t*)d_frames, d_slabs, frame_tag0, s, true, (e->cfg.flags & ZLY_FLAG_ASYNC_NMS) != 0);
     if (rc != ZLY_OK) { e->stats.inference_errors++; return rc; }
     e->stats.inference_count += (uint64_t)n;
     return ZLY_OK;
+}
+
+int32_t zly_join(zly_engine* e, void* stream, int32_t lag)
+{
+    if (!e) return fail(ZLY_ERR_NOT_INITIALIZED, "Engine not running");
+    if (lag < 0) return fail(ZLY_ERR_INVALID_ARGUMENT, "lag must be >= 0");
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIP_TRY(hipSetDevice(e->dev), ZLY_ERR_SYSTEM);
+    return join_nms(e, stream ? (hipStream_t)stream : e->stream, lag);
 }
 
 size_t zly_slab_bytes(const zly_engine* e) { return e ? slab_bytes_of(e) : 0; }
@@ -839,6 +906,7 @@ int32_t zly_sync(zly_engine* e)
     if (!e) return fail(ZLY_ERR_NOT_INITIALIZED, "Engine not running");
     HIP_TRY(hipSetDevice(e->dev), ZLY_ERR_SYSTEM);
     HIP_TRY(hipStreamSynchronize(e->stream), ZLY_ERR_INFERENCE);
+    if (e->nms_stream) HIP_TRY(hipStreamSynchronize(e->nms_stream), ZLY_ERR_INFERENCE);
     return ZLY_OK;
 }
 
@@ -848,6 +916,7 @@ int32_t zly_read_slabs(zly_engine* e, int32_t n, void* host_slabs)
     if (!host_slabs || n < 1 || n > e->cfg.max_batch) return fail(ZLY_ERR_INVALID_ARGUMENT, "bad argument");
     std::lock_guard<std::mutex> lk(e->mu);
     HIP_TRY(hipSetDevice(e->dev), ZLY_ERR_SYSTEM);
+    { int rcj = join_nms(e, e->stream); if (rcj != ZLY_OK) return rcj; }
     HIP_TRY(hipMemcpyAsync(host_slabs, e->d_slabs, slab_bytes_of(e) * (size_t)n, hipMemcpyDeviceToHost, e->stream), ZLY_ERR_INFERENCE);
     HIP_TRY(hipStreamSynchronize(e->stream), ZLY_ERR_INFERENCE);
     return ZLY_OK;

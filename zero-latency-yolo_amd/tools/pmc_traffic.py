@@ -1,5 +1,5 @@
 """HBM-side traffic per batch step from two rocprofv3 counter passes (MI355X_MICROARCH.md, HBM / rocprofv3 section):
-    rocprofv3 --pmc FETCH_SIZE --kernel-trace -d DIR_R -- python3 bench.py --batch 64 --steps 6 --warmup 1 --no-extras --no-cpu-baseline
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d DIR_R -- python3 bench.py --batch 64 --steps 6 --warmup 1 --no-extras --no-cpu-baseline
     rocprofv3 --pmc WRITE_SIZE --kernel-trace -d DIR_W -- python3 bench.py ... (same command)
     python3 tools/pmc_traffic.py DIR_R DIR_W profiles/rNN_traffic_b64.json
 FETCH_SIZE / WRITE_SIZE are in KiB-like units of 1 KB per count as rocprofv3 reports them; gfx950 correction: FETCH_SIZE x 2.

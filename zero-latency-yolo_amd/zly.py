@@ -28,11 +28,12 @@ SLAB_OVERFLOW = 1
 FLAG_DUMP_LOGITS = 1
 FLAG_NO_FUSION = 2
 FLAG_NO_HEAD_TENSOR = 4
+FLAG_ASYNC_NMS = 8
 
 # every symbol include/zly.h declares (tests/test_abi.py checks the library exports them all)
 SYMBOLS = [
     "zly_default_config", "zly_create", "zly_destroy", "zly_last_error", "zly_version",
-    "zly_detect", "zly_detect_batch", "zly_detect_device", "zly_slab_bytes", "zly_read_slabs", "zly_sync",
+    "zly_detect", "zly_detect_batch", "zly_detect_device", "zly_slab_bytes", "zly_read_slabs", "zly_sync", "zly_join",
     "zly_preprocess", "zly_forward", "zly_head_tensor", "zly_postprocess", "zly_debug_tap",
     "zly_num_classes", "zly_num_anchors", "zly_num_ops", "zly_op_info_at", "zly_profile_ops", "zly_get_stats",
 ]
@@ -93,6 +94,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.zly_slab_bytes.argtypes = [vp]; lib.zly_slab_bytes.restype = sz
     lib.zly_read_slabs.argtypes = [vp, i32, vp]; lib.zly_read_slabs.restype = i32
     lib.zly_sync.argtypes = [vp]; lib.zly_sync.restype = i32
+    lib.zly_join.argtypes = [vp, vp, i32]; lib.zly_join.restype = i32
     lib.zly_preprocess.argtypes = [vp, vp, sz, i32, i32, vp]; lib.zly_preprocess.restype = i32
     lib.zly_forward.argtypes = [vp, i32, vp, vp]; lib.zly_forward.restype = i32
     lib.zly_head_tensor.argtypes = [vp, i32, vp]; lib.zly_head_tensor.restype = i32
@@ -183,6 +185,10 @@ class Engine:
 
     def sync(self):
         _check(self.lib, self.lib.zly_sync(self.h))
+
+    def join(self, stream: int = 0, lag: int = 0):
+        """FLAG_ASYNC_NMS: make `stream` wait (on the device) for the NMS of every call so far but the last `lag`"""
+        _check(self.lib, self.lib.zly_join(self.h, stream or None, lag))
 
     def read_slabs(self, n: int) -> List[Tuple[np.ndarray, np.ndarray]]:
         raw = np.zeros(n * self.slab_bytes, dtype=np.uint8)
