@@ -79,6 +79,59 @@ __device__ __forceinline__ void epilogue_px(const ConvArgs& a, f32x4 (&v)[CT], c
     }
 }
 
+// Epilogue of the LDS-tiled kernel (bf16 NHWC output): same arithmetic and channel pairing as epilogue_px, but addresses
+// are 32-bit byte offsets into buffer resources (no 64-bit multiply-add per store; out-of-range is the hardware's check)
+// and the stores carry their offset in the VGPR operand (see the store-hazard note in conv1x1_stream_kernel).
+template <int CT>
+__device__ __forceinline__ void epilogue_px_buf(const ConvArgs& a, __amdgpu_buffer_rsrc_t rout, __amdgpu_buffer_rsrc_t rres,
+                                                f32x4 (&v)[CT], const f32x4 (&bias)[CT], int tile0, int kq, int m)
+{
+    const int ntiles = (a.Cout + 15) >> 4;
+    const int paired = (ntiles >> 1) << 1;
+    const int ob = (m * a.out_cs + a.out_co) * 2;
+    const int rb = (m * a.res_cs + a.res_co) * 2;
+    f32x4 o[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        f32x4 x = v[c] + bias[c];
+        if (a.act) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[r] = silu<bf16_t>(x[r]);
+        }
+        o[c] = x;
+    }
+    const bool even0 = (tile0 & 1) == 0;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        const int tile = tile0 + c;
+        const int ch = tile_channel(tile, kq, paired);
+        if (ch >= a.Cout) continue;
+        const bool pair_here = even0 && (c % 2 == 0) && (c + 1 < CT) && (tile + 1 < paired);
+        if (pair_here) {
+            f32x4 lo = o[c], hi = o[c + 1 < CT ? c + 1 : c];
+            if (a.res) {
+                const bf16x8 r = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rres, rb + ch * 2, 0, 0));
+                lo += f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
+                hi += f32x4{(float)r[4], (float)r[5], (float)r[6], (float)r[7]};
+            }
+            bf16x8 w;
+            w[0] = (bf16_t)lo[0]; w[1] = (bf16_t)lo[1]; w[2] = (bf16_t)lo[2]; w[3] = (bf16_t)lo[3];
+            w[4] = (bf16_t)hi[0]; w[5] = (bf16_t)hi[1]; w[6] = (bf16_t)hi[2]; w[7] = (bf16_t)hi[3];
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, w), rout, ob + ch * 2, 0, 0);
+        } else if (!(even0 && (c % 2 == 1) && (tile < paired))) {      // second tile of a pair already written above
+            f32x4 x = o[c];
+            if (a.res) {
+                const bf16x4 r = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(rres, rb + ch * 2, 0, 0));
+                x += f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
+            }
+            bf16x4 w;
+            w[0] = (bf16_t)x[0]; w[1] = (bf16_t)x[1]; w[2] = (bf16_t)x[2]; w[3] = (bf16_t)x[3];
+            typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, w), rout, ob + ch * 2, 0, 0);
+        }
+    }
+}
+
 // MODE 0: 1x1 conv.  MODE 1: 3x3, Cin % KSTEP == 0 (a k-step never straddles a tap; tap/ci advance
 // incrementally).  MODE 2: 3x3, any Cin % EPL == 0 (tap = k / Cin by reciprocal multiply).
 // One wave owns PT 16-pixel tiles x CT 16-channel tiles.
@@ -426,7 +479,7 @@ template <int S, int PT> struct LdsGeom {
 };
 
 template <int S, int CT, int PT>
-__global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const ConvArgs a, int tiles_x, int tiles_per_img, int total_tiles)
+__global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const ConvArgs a, int tiles_x, int tiles_per_img, int total_tiles, int wres)
 {
     typedef LdsGeom<S, PT> G;
     constexpr int PW = G::PW, PITCH = G::PITCH;
@@ -462,10 +515,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const ConvArgs a, i
         const int t = ti / CT, ct = ti - t * CT;
         uwsrc[i] = (ct * a.nk + t * nchunks) * 512 + l * 8;
     }
-    // Cin == 32: one chunk, so every item of this workgroup uses the SAME weight tiles: they are staged with the
-    // first item only (weights were 2/3 of the bytes staged per item; staging costs ~1/64 + 1/79 cycles per byte per CU)
-    const bool w_once = nchunks == 1;
-    bool w_staged = false;
+    // wres: the weight tiles of ALL chunks of this workgroup's channel block fit in LDS next to the patch (host decision:
+    // Cin / 32 x 9 x CT KiB): they are copied once, before the item loop, and items stage the patch only.  Weights were
+    // 2/3 of the bytes staged per item (staging costs ~1/64 + 1/79 cycles per byte per CU): with them resident a
+    // 64 -> 64 layer runs as 2 channel blocks of CT = 2 that stage 17 KB per item instead of one block staging 54 KB.
+    const bool w_once = wres != 0;
+    bool w_staged = w_once;
+    if (w_once) {
+        for (int c = 0; c < nchunks; ++c) {
+            const bf16_t* wc = wbase + c * 512;
+#pragma unroll
+            for (int i = 0; i < NWU_T; ++i) {
+                const int u = tid + i * 256;
+                if (u < NWU) *reinterpret_cast<u32x4*>(lw + (size_t)c * (NWU * 16) + u * 16) = *reinterpret_cast<const u32x4*>(wc + uwsrc[i]);
+            }
+        }
+    }
     auto stage_load = [&](int tl, int c, u32x4 (&rp)[NPU_T], u32x4 (&rw)[NWU_T]) {
         const int b = tl / tiles_per_img;
         const int r = tl - b * tiles_per_img;
@@ -480,7 +545,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const ConvArgs a, i
                 v = *reinterpret_cast<const u32x4*>(inb + usrc[i]);
             rp[i] = v;
         }
-        if (w_once && tl != (int)blockIdx.x) return;          // only the workgroup's first item carries weights
+        if (w_once) return;                                   // weights are resident
         const bf16_t* wc = wbase + c * 512;
 #pragma unroll
         for (int i = 0; i < NWU_T; ++i) rw[i] = *reinterpret_cast<const u32x4*>(wc + uwsrc[i]);
@@ -508,6 +573,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const ConvArgs a, i
 
     f32x4 biasr[CT];
     load_bias<CT>(a, blockIdx.y * CT, kq, biasr);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (unsigned)((size_t)a.M * a.out_cs * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.res ? a.res : a.out), 0,
+                                                                          (unsigned)((size_t)a.M * (a.res ? a.res_cs : a.out_cs) * 2), 0x00020000);
 #ifdef ZLY_DIAG
     unsigned long long dsum[6] = {0, 0, 0, 0, 0, 0}, ditems = 0, dT0 = 0, dT1 = 0;
 #define ZSTAMP(t) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -516,7 +584,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const ConvArgs a, i
     // 9 taps of one staged chunk; the epilogue runs after a tile's last chunk
     auto compute = [&](int tl, int c) {
 #if ZLY_TAPS_DEPTH > 0
-        taps_mma<CT, PT, S, PW, PITCH>(lpatch, lw, lane, wave * PT, p, kq, acc);
+        taps_mma<CT, PT, S, PW, PITCH>(lpatch, w_once ? lw + (size_t)c * (NWU * 16) : lw, lane, wave * PT, p, kq, acc);
 #else
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
@@ -524,7 +592,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const ConvArgs a, i
             bf16x8 wf[CT], af[PT];
 #pragma unroll
             for (int cc = 0; cc < CT; ++cc)
-                wf[cc] = *reinterpret_cast<const bf16x8*>(lw + (t * CT + cc) * 1024 + lane * 16);
+                wf[cc] = *reinterpret_cast<const bf16x8*>((w_once ? lw + (size_t)c * (NWU * 16) : lw) + (t * CT + cc) * 1024 + lane * 16);
 #pragma unroll
             for (int i = 0; i < PT; ++i) {
                 const int row = wave * PT + i;
@@ -552,7 +620,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const ConvArgs a, i
 #pragma unroll
             for (int cc = 0; cc < CT; ++cc) { v[cc] = acc[cc][i]; acc[cc][i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
             if (oy >= a.Ho || ox >= a.Wo) continue;
-            epilogue_px<bf16_t, CT>(a, v, biasr, blockIdx.y * CT, kq, (b * a.Ho + oy) * a.Wo + ox);
+            epilogue_px_buf<CT>(a, rout, rres, v, biasr, blockIdx.y * CT, kq, (b * a.Ho + oy) * a.Wo + ox);
         }
     };
 
@@ -621,7 +689,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const ConvArgs a, i
 #endif
 }
 
-typedef void (*conv_lds_fn)(const ConvArgs, int, int, int);
+typedef void (*conv_lds_fn)(const ConvArgs, int, int, int, int);
 
 template <int S, int PT>
 static conv_lds_fn pick_lds_ct(int ct) {
@@ -637,11 +705,11 @@ static conv_lds_fn pick_lds(int stride, int pt, int ct) {
     if (stride == 1) return pt == 1 ? pick_lds_ct<1, 1>(ct) : pt == 2 ? pick_lds_ct<1, 2>(ct) : pick_lds_ct<1, 4>(ct);
     return pt == 1 ? pick_lds_ct<2, 1>(ct) : pick_lds_ct<2, 2>(ct);
 }
-static size_t lds_bytes(int stride, int pt, int ct) {
+static size_t lds_bytes(int stride, int pt, int ct, int wchunks = 1) {
     size_t patch = 0;
     if (stride == 1) patch = pt == 1 ? LdsGeom<1, 1>::PATCH_BYTES : pt == 2 ? LdsGeom<1, 2>::PATCH_BYTES : LdsGeom<1, 4>::PATCH_BYTES;
     else             patch = pt == 1 ? LdsGeom<2, 1>::PATCH_BYTES : LdsGeom<2, 2>::PATCH_BYTES;
-    return patch + (size_t)9 * ct * 1024;
+    return patch + (size_t)wchunks * 9 * ct * 1024;
 }
 
 // dynamic LDS above 64 KiB needs an opt-in per kernel; done once, outside any stream capture
@@ -650,7 +718,7 @@ hipError_t conv_init()
     static const int pts1[3] = {1, 2, 4}, pts2[2] = {1, 2};
     for (int ct = 2; ct <= 5; ++ct) {
         for (int i = 0; i < 3; ++i) {
-            hipError_t r = hipFuncSetAttribute((const void*)pick_lds(1, pts1[i], ct), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(1, pts1[i], ct));
+            hipError_t r = hipFuncSetAttribute((const void*)pick_lds(1, pts1[i], ct), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(1, pts1[i], ct, 2));
             if (r != hipSuccess) return r;
         }
         for (int i = 0; i < 2; ++i) {
@@ -702,11 +770,25 @@ static bool pick_lds_config(int stride, int cin, int cout_pad, int n, int Ho, in
     for (int i = 0; i < 4; ++i)
         if (ntiles % pref[i] == 0) { ct = pref[i]; break; }
     if (!ct) return false;
+    // resident weights (stride 1, Cin 32 / 64) when the weights of ALL chunks of the preferred channel block fit beside the
+    // patch with two workgroups per CU (<= 80 KB each): Cin = 32 always, Cin = 64 with CT = 3 (the 144-channel Detect
+    // stems, 54 KB).  Measured (tools/diag_lds.hip): 64 -> 144 at 52x52: 71 -> 63 us; halving CT to make 64 -> 64 resident
+    // (CT = 2 x 2 channel blocks, patch staged twice) was slower than CT = 4 with per-item weights: 37 vs 32 us.
+    cfg->wres = 0;
+    const char* nr = getenv("ZLY_NO_WRES");
+    if (stride == 1 && cin <= 64 && !nr) {
+        static const int rpref[4] = {4, 3, 2, 5};
+        for (int i = 0; i < 4; ++i) {
+            const int c = rpref[i];
+            if (ntiles % c == 0 && c >= ct && (size_t)(cin / 32) * 9 * c * 1024 + LdsGeom<1, 2>::PATCH_BYTES <= 80 * 1024) { ct = c; cfg->wres = 1; break; }
+        }
+    }
     const int ytiles = ntiles / ct;
     const int tx = (Wo + 15) / 16;
     int pt = stride == 1 ? 2 : 1;
     if (stride == 1 && ct == 2 && (long)n * tx * ((Ho + 15) / 16) * ytiles >= 2048) pt = 4;   // plenty of tiles, few channels: bigger tiles (VGPR budget)
     if (stride == 1 && Ho <= 14) pt = 1;                                            // 13-row maps: 4 x 4 rows
+    if (ct == 5 && (pt > 1 || stride == 2)) { if (stride == 2) return false; pt = 1; }  // those variants do not fit 256 registers (2 waves per SIMD) without spilling
     const long tiles = (long)n * tx * ((Ho + 4 * pt - 1) / (4 * pt));
     if (tiles * ytiles < 384) return false;                                         // too small: direct kernel
     cfg->lds = 1; cfg->ct = ct; cfg->pt = pt; cfg->ksplit = 1; cfg->fastk = 1;
@@ -732,7 +814,7 @@ static bool pick_stream_config(int cin, int cout_pad, int M, ConvLaunch* cfg)
 void conv_pick_config(int dtype, int ks, int stride, int cin, int cout_pad, int n, int Ho, int Wo, ConvLaunch* cfg, bool streamable)
 {
     const int M = n * Ho * Wo;
-    cfg->ks = ks; cfg->lds = 0; cfg->stream = 0;
+    cfg->ks = ks; cfg->lds = 0; cfg->stream = 0; cfg->wres = 0;
     const bool no_stream = getenv("ZLY_NO_STREAM") != nullptr;             // tuning / tests
     if (dtype == ZLY_DTYPE_BF16 && ks == 1 && stride == 1 && streamable && !no_stream && pick_stream_config(cin, cout_pad, M, cfg)) return;
     if (dtype == ZLY_DTYPE_BF16 && ks == 3 && pick_lds_config(stride, cin, cout_pad, n, Ho, Wo, cfg)) return;
@@ -742,7 +824,7 @@ void conv_pick_config(int dtype, int ks, int stride, int cin, int cout_pad, int 
 void conv_pick_direct(int dtype, int ks, int cin, int cout_pad, int M, ConvLaunch* cfg)
 {
     const int kstep = conv_kstep(dtype);
-    cfg->ks = ks; cfg->stream = 0;
+    cfg->ks = ks; cfg->stream = 0; cfg->wres = 0;
     cfg->fastk = (ks == 3 && cin % kstep == 0) ? 1 : 0;
     cfg->ksplit = 1;
     const int ntiles = cout_pad / 16;
@@ -786,7 +868,9 @@ hipError_t launch_conv(int dtype, const ConvArgs& a, const ConvLaunch& cfg, hipS
         const int max_wgs = 2 * 256;                       // two resident workgroups per CU (LDS / VGPR budget)
         if (gx * ytiles > max_wgs) gx = max_wgs / ytiles;  // never more than are resident: a persistent workgroup
         if (gx > total) gx = total;                        // that has to wait for a slot runs a whole round alone
-        hipLaunchKernelGGL(fn, dim3(gx, ytiles, 1), dim3(256), lds_bytes(a.stride, cfg.pt, cfg.ct), s, a, tiles_x, tiles_per_img, total);
+        const int nchunks = a.Cin / 32;
+        if (cfg.wres && (a.stride != 1 || nchunks > 2)) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(fn, dim3(gx, ytiles, 1), dim3(256), lds_bytes(a.stride, cfg.pt, cfg.ct, cfg.wres ? nchunks : 1), s, a, tiles_x, tiles_per_img, total, cfg.wres);
         return hipGetLastError();
     }
     if (cfg.ks == 1 && (a.stride != 1 || a.pad != 0)) return hipErrorInvalidValue;      // the 1x1 paths assume input pixel = output pixel

@@ -39,7 +39,7 @@ struct ConvArgs {
     const void* in2;  int in2_cs, in2_co, split_c;
 };
 
-struct ConvLaunch { int ks, ct, pt, fastk, ksplit, lds, stream; };
+struct ConvLaunch { int ks, ct, pt, fastk, ksplit, lds, stream, wres; };
 
 // kernels_conv.hip
 hipError_t launch_conv(int dtype, const ConvArgs& a, const ConvLaunch& cfg, hipStream_t s);

@@ -10,7 +10,7 @@
 using namespace zly;
 
 template <int S, int CT, int PT>
-static void run(const char* name, int n, int H, int W, int Cin, int Cout)
+static void run(const char* name, int n, int H, int W, int Cin, int Cout, int wres = 0)
 {
     const int Ho = H / S, Wo = W / S;
     const int nk = 9 * Cin / 32, cout_pad = (Cout + 15) / 16 * 16;
@@ -35,7 +35,7 @@ static void run(const char* name, int n, int H, int W, int Cin, int Cout)
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int rep = 0; rep < 3; ++rep) {
         hipEventRecord(e0, 0);
-        hipLaunchKernelGGL((conv3x3_lds_kernel<S, CT, PT>), dim3(gx, ytiles), dim3(256), lds_bytes(S, PT, CT), 0, a, tiles_x, tpi, total);
+        hipLaunchKernelGGL((conv3x3_lds_kernel<S, CT, PT>), dim3(gx, ytiles), dim3(256), lds_bytes(S, PT, CT, wres ? Cin / 32 : 1), 0, a, tiles_x, tpi, total, wres);
         hipEventRecord(e1, 0); hipEventSynchronize(e1);
     }
     float ms = 0; hipEventElapsedTime(&ms, e0, e1);
@@ -107,6 +107,10 @@ int main()
     run<1, 3, 2>("52x52 64->144 (x64) P3 stem", 64, 52, 52, 64, 144);
     run<1, 4, 2>("52x52 64->64 (x64) box2", 64, 52, 52, 64, 64);
     run<1, 2, 2>("52x52 32->32 (x64)", 64, 52, 52, 32, 32);
+    run<1, 2, 2>("52x52 32->32 (x64) resident w", 64, 52, 52, 32, 32, 1);
+    run<1, 2, 2>("52x52 64->64 box2 CT=2 resident w", 64, 52, 52, 64, 64, 1);
+    run<1, 2, 2>("26x26 64->64 CT=2 resident w", 64, 26, 26, 64, 64, 1);
+    run<1, 3, 2>("52x52 64->144 P3 stem resident w", 64, 52, 52, 64, 144, 1);
     run<2, 4, 1>("104->52 s2 32->64 (x64)", 64, 104, 104, 32, 64);
     run<2, 4, 1>("52->26 s2 64->128 (x64)", 64, 52, 52, 64, 128);
     run<2, 4, 1>("26->13 s2 128->256 (x64)", 64, 26, 26, 128, 256);
