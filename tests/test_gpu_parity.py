@@ -443,7 +443,7 @@ def test_deferred_nms_same_slabs(weights_path):
     """ZLY_FLAG_ASYNC_NMS: NMS of call k runs on the engine's own stream beside call k+1.  Five calls with different
     batches and slab buffers must give byte-identical slabs to the in-order engine; zly_join / zly_read_slabs /
     zly_sync are the points where a call's slabs are complete."""
-    n = 8
+    n = 16                                            # deferral applies from batch 16 up
     sets = [zm.synth_frames(n, 416, 416, seed=50 + i, rects=False) for i in range(3)]
     dev = [torch.from_numpy(x).cuda() for x in sets]
     a = zly.Engine(weights_path, max_batch=n, max_dets=64, conf_thr=0.25, warmup_runs=1)
@@ -473,6 +473,12 @@ def test_deferred_nms_same_slabs(weights_path):
     b.detect_device(dev[1].data_ptr(), n, 416, 416, tag0=7)
     got = b.read_slabs(n)
     assert all(det_fields_equal(got[i][1], want[1][i][1]) for i in range(n))
+    b.detect_device(dev[0].data_ptr(), n, 416, 416, tag0=1)                       # deferred ...
+    b.detect_device(dev[2].data_ptr(), 4, 416, 416, tag0=9)                       # ... then a small, in-order call on the same engine
+    got = b.read_slabs(4)
+    a.detect_device(dev[2].data_ptr(), 4, 416, 416, tag0=9)
+    ref4 = a.read_slabs(4)
+    assert all(det_fields_equal(got[i][1], ref4[i][1]) for i in range(4))
     d1, n1 = b.detect(sets[2][3], cap=64)
     d2, n2 = a.detect(sets[2][3], cap=64)
     assert n1 == n2 and det_fields_equal(d1, d2)

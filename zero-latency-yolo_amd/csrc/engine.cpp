@@ -570,7 +570,9 @@ static int join_nms(zly_engine* e, hipStream_t s, int lag = 0)
 static int run_path(zly_engine* e, int n, const uint8_t* d_src, void* d_slabs_out, uint32_t tag0, hipStream_t s, bool with_pre, bool defer_nms = false)
 {
     const size_t nops = e->ops.size();
-    defer_nms = defer_nms && e->nms_stream != nullptr;
+    // like the Detect side streams: below batch 16 the cross-stream edges (event record + two stream waits per call) cost
+    // more than the overlap buys -- measured 0.236 -> 0.290 ms per frame at batch 1 -- so small batches stay in stream order
+    defer_nms = defer_nms && e->nms_stream != nullptr && n >= 16;
     int par = 0;
     if (defer_nms) {
         // this call's Detect tail fills candidate buffer `par`; the NMS that last read it (two calls back) must be done
