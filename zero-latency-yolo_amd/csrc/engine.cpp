@@ -539,7 +539,8 @@ static hipError_t run_ops(zly_engine* e, size_t first, size_t last, int n, const
         hipStream_t st = s;
         // measured: at batch 1 the cross-stream edges cost more than the overlap buys (0.27 -> 0.34 ms/frame);
         // from batch 16 up the Detect branches are long enough to pay (1.42 -> 1.38 ms per 64 frames)
-        if (op.lane > 0 && n >= 16) {
+        static const bool no_lanes = getenv("ZLY_NO_LANES") != nullptr;     // tuning aid
+        if (op.lane > 0 && n >= 16 && !no_lanes) {
             st = e->side[op.lane - 1];
             if (!forked[op.lane]) {
                 r = hipEventRecord(e->ev_fork[op.lane - 1], s);

@@ -2,13 +2,14 @@
 //
 // Replaces two launches and the HBM round trip of the preprocessed tensor: the reference materialises
 // preProcess's fp32 [3][416][416] tensor (onnx_engine.cpp:649-700) and hands it to the first ORT conv node.
-// Here a workgroup owns an 8 x 32 tile of stem outputs of one frame:
+// Here a workgroup owns a 16 x 32 tile of stem outputs of one frame (8 x 32 at first: the per-workgroup setup -- three
+// IEEE divides, weight fragments, tap offsets -- was a fifth of a wave's instructions in this issue-bound kernel):
 //   1. it fills a 256-entry table bf16(u8 / 255.0f) in LDS -- the exact value preProcess + bf16 rounding
 //      gives (:693), one IEEE divide per entry instead of three per pixel;
-//   2. stages the 17 x 65 input patch: for every model-space pixel the reference's nearest-neighbour map
+//   2. stages the 33 x 65 input patch: for every model-space pixel the reference's nearest-neighbour map
 //      src = (min(int(y*scale_h), h-1), min(int(x*scale_w), w-1)) (:673-685), BGR->RGB through the table,
 //      as {R,G,B,0} bf16 = 8 bytes per pixel, zero outside the frame (conv padding);
-//   3. each wave computes 4 x 16 output pixels with v_mfma_f32_16x16x32_bf16: K = 9 taps x 4 channels
+//   3. each wave computes 8 x 16 output pixels with v_mfma_f32_16x16x32_bf16: K = 9 taps x 4 channels
 //      padded to 2 k-steps; the stem's whole weight matrix (2 KiB) stays in 2 fragment registers per lane
 //      for the kernel's lifetime (weight-stationary), activations come from LDS as two 8-byte reads per
 //      fragment (two taps x 4 channels);
@@ -21,7 +22,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-#define STEM_TH 8
+#define STEM_TH 16
 #define STEM_TW 32
 #define STEM_PH (STEM_TH * 2 + 1)
 #define STEM_PW (STEM_TW * 2 + 1)
@@ -50,13 +51,17 @@ __global__ __launch_bounds__(256) void stem_fused_kernel(const StemArgs a)
     const float scale_w = (float)d.w / (float)a.tw;
     const float scale_h = (float)d.h / (float)a.th;
     const uint8_t* src = a.src + d.src_off;
+    const bool same = d.w == a.tw && d.h == a.th;
     for (int u = tid; u < STEM_PH * STEM_PW; u += 256) {
         const int py = u / STEM_PW, px = u - py * STEM_PW;
         const int iy = iy0 + py, ix = ix0 + px;
         bf16x4 v = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
         if ((unsigned)iy < (unsigned)a.th && (unsigned)ix < (unsigned)a.tw) {
-            int sy = (int)((float)iy * scale_h); if (sy > d.h - 1) sy = d.h - 1;
-            int sx = (int)((float)ix * scale_w); if (sx > d.w - 1) sx = d.w - 1;
+            int sy = iy, sx = ix;
+            if (!same) {       // request size == model size: the nearest-neighbour map is the identity (wave-uniform branch)
+                sy = (int)((float)iy * scale_h); if (sy > d.h - 1) sy = d.h - 1;
+                sx = (int)((float)ix * scale_w); if (sx > d.w - 1) sx = d.w - 1;
+            }
             const uint8_t* q = src + ((size_t)sy * d.w + sx) * 3;
             v[0] = lut[q[2]]; v[1] = lut[q[1]]; v[2] = lut[q[0]];        // BGR -> RGB
         }
@@ -78,8 +83,8 @@ __global__ __launch_bounds__(256) void stem_fused_kernel(const StemArgs a)
 
     const f32x4 bias = *reinterpret_cast<const f32x4*>(a.bias + kq * 4);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = wave * 2 + (i >> 1), col = (i & 1) * 16 + p;
+    for (int i = 0; i < 8; ++i) {
+        const int row = wave * 4 + (i >> 1), col = (i & 1) * 16 + p;
         const int base = (row * 2) * STEM_PW + col * 2;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
