@@ -30,6 +30,18 @@ __device__ __forceinline__ f32x4 hmma(f32x4 a, f32x4 b, f32x4 c) {
     return c;
 }
 
+// exp / reciprocal of the DFL softmax and the class sigmoid.  fp32 engine (verification mode): libm expf and IEEE divides.
+// bf16 engine: v_exp_f32 / v_rcp_f32 (1 ulp) -- the 36 expf + 24 divides per lane were half of this kernel's time
+// (~900 VALU instructions per 16 anchors); the inputs carry bf16 rounding noise four orders of magnitude larger.
+// Whatever is computed here is what goes into the head tensor AND into the threshold/arg-max, so detect() stays
+// bit-identical to the oracle's post-processing of the engine's own head tensor.
+template <typename T> __device__ __forceinline__ float h_exp(float x);
+template <> __device__ __forceinline__ float h_exp<float>(float x) { return expf(x); }
+template <> __device__ __forceinline__ float h_exp<bf16_t>(float x) { return __builtin_amdgcn_exp2f(x * 1.442695041f); }
+template <typename T> __device__ __forceinline__ float h_div(float a, float b);
+template <> __device__ __forceinline__ float h_div<float>(float a, float b) { return a / b; }
+template <> __device__ __forceinline__ float h_div<bf16_t>(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+
 // One wave = 16 anchors (MFMA columns).  Lane (p = lane & 15, kq = lane >> 4) ends up holding, for
 // every 16-channel tile c, channels c*16 + kq*4 + {0..3} of anchor p.
 template <typename T, int CTC>
@@ -102,13 +114,13 @@ __global__ __launch_bounds__(256) void head_fused_kernel(const HeadArgs a)
         float se = 0.f, sw = 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float e = expf(v[r] - m);
+            const float e = h_exp<T>(v[r] - m);
             se += e;
             sw += e * (float)(kq * 4 + r);
         }
         se += __shfl_xor(se, 16); sw += __shfl_xor(sw, 16);
         se += __shfl_xor(se, 32); sw += __shfl_xor(sw, 32);
-        dist[c] = sw / se;
+        dist[c] = h_div<T>(sw, se);
     }
     const float ax = (float)(an % L.W) + 0.5f, ay = (float)(an / L.W) + 0.5f;
     const float x1 = ax - dist[0], y1 = ay - dist[1], x2 = ax + dist[2], y2 = ay + dist[3];
@@ -127,7 +139,7 @@ __global__ __launch_bounds__(256) void head_fused_kernel(const HeadArgs a)
         accc[c] = z;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float sc = 1.0f / (1.0f + expf(-z[r]));
+            const float sc = h_div<T>(1.0f, 1.0f + h_exp<T>(-z[r]));
             score[c][r] = sc;
             if (ch + r < a.nc && sc > best) { best = sc; cls = ch + r; }
         }
