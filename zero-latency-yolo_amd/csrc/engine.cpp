@@ -372,8 +372,18 @@ static int build_plan(zly_engine* e, std::string* err)
         e->lvl_h[l] = fh[l]; e->lvl_w[l] = fw[l];
         anchor_off += fh[l] * fw[l];
     }
-    hd.head.nc = m.nc; hd.head.N_total = e->N; hd.head.total_blocks = block0;
-    if (ok) e->ops.push_back(hd);
+    hd.head.nc = m.nc; hd.head.N_total = e->N; hd.head.total_blocks = block0; hd.head.only_level = -1;
+    // Three tail ops, one per level.  From batch 16 up each is its own launch right behind its level's branch convs (P3 and
+    // P4 on the side streams, i.e. beside the neck) and only the small P5 launch is left at the end of the step; below
+    // that the first two are skipped and the last one covers all levels in a single launch (fewest launches).
+    for (int l = 0; l < 3 && ok; ++l) {
+        Op t = hd;
+        t.level = l;
+        t.name = std::string("detect.tail.P") + std::to_string(3 + l) + (l == 2 ? " (all levels below batch 16)" : "");
+        const double share = (double)hd.head.lv[l].hw / (double)e->N;
+        t.flops = hd.flops * share; t.bytes = hd.bytes * share;
+        e->ops.push_back(t);
+    }
     if (!ok) { *err = pb.err; return ZLY_ERR_MODEL_LOAD; }
     Op nm; nm.kind = OP_NMS; nm.name = "nms"; e->ops.push_back(nm);
 
@@ -389,6 +399,7 @@ static int build_plan(zly_engine* e, std::string* err)
                 const int lvl = op.name[13] - '0';                 // "model.22.cvX.L...": L is character 13
                 lane = lvl == 0 ? 1 : (lvl == 1 ? 2 : 0);
             }
+            if (op.kind == OP_HEAD) lane = op.level == 0 ? 1 : (op.level == 1 ? 2 : 0);
             op.lane = lane;
             (lane == 0 ? main_ops : lane_ops[lane]).push_back(op);
         }
@@ -438,6 +449,14 @@ static int build_plan(zly_engine* e, std::string* err)
 // ------------------------------------------------------------------------------------------------
 // execution
 // ------------------------------------------------------------------------------------------------
+// Detect branches on side streams (and per-level tail launches): measured at batch 1 the cross-stream edges cost more
+// than the overlap buys (0.27 -> 0.34 ms/frame); from batch 16 up the branches are long enough to pay
+static bool lanes_active(int n)
+{
+    static const bool no_lanes = getenv("ZLY_NO_LANES") != nullptr;     // tuning aid
+    return n >= 16 && !no_lanes;
+}
+
 // Fused bottleneck pair for this op at batch n?  Small launches (few tiles) stay on the per-conv kernels, which
 // split a layer into many more workgroups.  Same answer for both ops of a pair.
 static const PairPlan* pair_active(zly_engine* e, const Op& op, int n)
@@ -510,6 +529,10 @@ static hipError_t run_op(zly_engine* e, const Op& op, int n, const uint8_t* d_sr
     }
     case OP_HEAD: {
         HeadArgs h = op.head;
+        static const bool no_split = getenv("ZLY_NO_TAIL_SPLIT") != nullptr;   // tuning aid
+        if (lanes_active(n) && !no_split) h.only_level = op.level;       // per-level launches (+0.3 % at batch 64)
+        else if (op.level != 2) return hipSuccess;          // the last tail op covers all levels
+        else h.only_level = -1;
         h.head = (e->cfg.flags & ZLY_FLAG_NO_HEAD_TENSOR) ? nullptr : e->d_head; h.desc = e->d_desc; h.conf_thr = e->cfg.conf_thr; h.cand = e->cur_cand; h.cand_count = e->cur_count;
         return launch_head_fused(e->dtype, h, n, s);
     }
@@ -539,8 +562,7 @@ static hipError_t run_ops(zly_engine* e, size_t first, size_t last, int n, const
         hipStream_t st = s;
         // measured: at batch 1 the cross-stream edges cost more than the overlap buys (0.27 -> 0.34 ms/frame);
         // from batch 16 up the Detect branches are long enough to pay (1.42 -> 1.38 ms per 64 frames)
-        static const bool no_lanes = getenv("ZLY_NO_LANES") != nullptr;     // tuning aid
-        if (op.lane > 0 && n >= 16 && !no_lanes) {
+        if (op.lane > 0 && lanes_active(n)) {
             st = e->side[op.lane - 1];
             if (!forked[op.lane]) {
                 r = hipEventRecord(e->ev_fork[op.lane - 1], s);
@@ -549,7 +571,7 @@ static hipError_t run_ops(zly_engine* e, size_t first, size_t last, int n, const
                 if (r != hipSuccess) break;
             }
         }
-        if (op.kind == OP_HEAD || op.kind == OP_NMS) { join_all(); if (r != hipSuccess) break; }
+        if (op.kind == OP_NMS) { join_all(); if (r != hipSuccess) break; }       // the tail launches only append candidates: no join needed before them
         r = run_op(e, op, n, d_src, d_slabs_out, tag0, st);
     }
     if (r == hipSuccess) join_all();

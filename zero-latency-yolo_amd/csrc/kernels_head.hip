@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void head_fused_kernel(const HeadArgs a)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int p = lane & 15, kq = lane >> 4;
     const int f = blockIdx.y;
-    const int bx = blockIdx.x;
+    const int bx = blockIdx.x + (a.only_level >= 0 ? a.lv[a.only_level].block0 : 0);
     const int li = bx >= a.lv[2].block0 ? 2 : (bx >= a.lv[1].block0 ? 1 : 0);
     const HeadLevel& L = a.lv[li];
     const int anchor0 = (bx - L.block0) * 64 + wave * 16;
@@ -211,7 +211,9 @@ hipError_t launch_head_fused(int dtype, const HeadArgs& a, int n, hipStream_t s)
     const int ctc = (a.nc + 15) / 16;
     head_fn fn = dtype == ZLY_DTYPE_BF16 ? pick_head<bf16_t>(ctc) : pick_head<float>(ctc);
     if (!fn) return hipErrorInvalidValue;                  // nc > 80 is not supported by this kernel
-    hipLaunchKernelGGL(fn, dim3(a.total_blocks, n), dim3(256), 0, s, a);
+    if (a.only_level > 2) return hipErrorInvalidValue;
+    const int blocks = a.only_level >= 0 ? (a.lv[a.only_level].hw + 63) / 64 : a.total_blocks;
+    hipLaunchKernelGGL(fn, dim3(blocks, n), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

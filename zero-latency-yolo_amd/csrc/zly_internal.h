@@ -93,6 +93,7 @@ struct HeadLevel {
 struct HeadArgs {
     HeadLevel lv[3];
     int nc, N_total, total_blocks;
+    int only_level;                           // -1: all three levels in one launch; 0..2: that level only (its own launch, beside the neck)
     float* head;                              // [n][4+nc][N_total] or null
     const FrameDesc* desc; float conf_thr;
     struct Cand* cand; int* cand_count;
