@@ -477,6 +477,14 @@ static const PairPlan* pair_active(zly_engine* e, const Op& op, int n)
     return it->second.first ? &it->second.second : nullptr;
 }
 
+// ops that launch nothing at this batch size (second conv of a fused pair; per-level tail ops when one launch covers all)
+static bool op_is_noop(zly_engine* e, const Op& op, int n)
+{
+    if (op.kind == OP_CONV && op.pair == 2) return pair_active(e, op, n) != nullptr;
+    if (op.kind == OP_HEAD && op.level != 2) return !lanes_active(n) || getenv("ZLY_NO_TAIL_SPLIT") != nullptr;
+    return false;
+}
+
 static hipError_t run_op(zly_engine* e, const Op& op, int n, const uint8_t* d_src, void* d_slabs_out, uint32_t tag0, hipStream_t s)
 {
     switch (op.kind) {
@@ -1157,6 +1165,7 @@ int32_t zly_profile_ops(zly_engine* e, int32_t n, const void* d_frames, int32_t 
         for (size_t i = 0; i < nops; ++i) {
             float ms = 0.f;
             hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
+            if (op_is_noop(e, e->ops[i], n)) ms = 0.f;       // nothing was launched: what the event pair shows is its own cost
             acc[i] += ms / ((e->ops[i].kind == OP_HEAD || e->ops[i].kind == OP_NMS) ? 1 : inner);
         }
     }
