@@ -397,6 +397,31 @@ def test_640x640_fp32_and_bf16(weights_path, oracle, ref_fp32):
     e.close()
 
 
+def test_640x640_batch_32_per_gpu_share(weights_path, oracle):
+    """BASELINE configs[3] as one GPU sees it: 640x640, 32 frames per step (batch 256 over 8 GPUs), the production flags
+    (fused bottlenecks, streaming 1x1, side streams, deferred NMS).  Size-independent properties: permutation
+    equivariance of the slabs, and detect() == the oracle's post-processing of the engine's own head tensor."""
+    n = 32
+    frames = zm.synth_frames(n, 640, 640, seed=91, rects=False)
+    e = zly.Engine(weights_path, model_w=640, model_h=640, max_batch=n, max_dets=128, warmup_runs=1, flags=zly.FLAG_ASYNC_NMS)
+    d = torch.from_numpy(frames).cuda()
+    e.detect_device(d.data_ptr(), n, 640, 640)
+    slabs = e.read_slabs(n)
+    perm = np.random.default_rng(1).permutation(n)
+    d2 = torch.from_numpy(frames[perm]).cuda()
+    e.detect_device(d2.data_ptr(), n, 640, 640)
+    slabs2 = e.read_slabs(n)
+    for i in range(n):
+        assert slabs2[i][0]["n_kept"] == slabs[perm[i]][0]["n_kept"] and det_fields_equal(slabs2[i][1], slabs[perm[i]][1])
+    e.detect_device(d.data_ptr(), n, 640, 640)
+    slabs = e.read_slabs(n)
+    for i in (0, 13, n - 1):
+        want = oracle.postprocess(e.head_tensor(i), 640, 640)
+        assert slabs[i][0]["n_kept"] == len(want) and det_fields_equal(slabs[i][1], want[:128])
+    assert sum(int(s_[0]["n_kept"]) for s_ in slabs) > 0
+    e.close()
+
+
 def test_yolov8s_widths(tmp_path, oracle):
     """YOLOv8-s channel widths (32..512, Detect class branch 128 wide): the plan builder, tile pickers and the
     fused Detect tail are generic in the widths; the 32-channel stem takes the unfused preprocess + conv path."""
