@@ -58,7 +58,7 @@ def host_cores():
 FORCE_GATHER = os.environ.get("ZLY_BENCH_FORCE_GATHER") == "1"
 
 
-def run_steps(eng, frame_sets, batch, steps, slabs, stream_ptr, world, gather_out):
+def run_steps(eng, frame_sets, batch, steps, slabs, stream_ptr, world, gather_out, size=416):
     """enqueue `steps` steps.  The engine runs NMS of step k on its own stream beside the first kernels of step k+1
     (ZLY_FLAG_ASYNC_NMS); with world > 1 the slabs of step k are all-gathered once step k+1 has been enqueued:
     zly_join orders the stream behind NMS(k), then the collective is queued -- overlapped with step k+1."""
@@ -74,7 +74,7 @@ def run_steps(eng, frame_sets, batch, steps, slabs, stream_ptr, world, gather_ou
 
     for k in range(steps):
         d = frame_sets[k % len(frame_sets)]
-        eng.detect_device(d.data_ptr(), batch, 416, 416, d_slabs_ptr=slabs[k % 3].data_ptr(), tag0=k * batch, stream=stream_ptr)
+        eng.detect_device(d.data_ptr(), batch, size, size, d_slabs_ptr=slabs[k % 3].data_ptr(), tag0=k * batch, stream=stream_ptr)
         if gather and k > 0:
             gather_step(k - 1, 1)                      # NMS(k-1), not NMS(k): step k+1 must not queue behind NMS(k)
     if gather and steps > 0:
@@ -84,15 +84,15 @@ def run_steps(eng, frame_sets, batch, steps, slabs, stream_ptr, world, gather_ou
     eng.join(stream_ptr)                               # the last NMS is ordered into the timed stream
 
 
-def timed(eng, frame_sets, batch, steps, warmup, slabs, stream_ptr, world, gather_out):
+def timed(eng, frame_sets, batch, steps, warmup, slabs, stream_ptr, world, gather_out, size=416):
     import torch.distributed as dist
-    run_steps(eng, frame_sets, batch, warmup, slabs, stream_ptr, world, gather_out)
+    run_steps(eng, frame_sets, batch, warmup, slabs, stream_ptr, world, gather_out, size)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    run_steps(eng, frame_sets, batch, steps, slabs, stream_ptr, world, gather_out)
+    run_steps(eng, frame_sets, batch, steps, slabs, stream_ptr, world, gather_out, size)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -171,6 +171,7 @@ def run():
     ap.add_argument("--no-extras", action="store_true", help="skip the batch-64 / latency / roofline legs")
     ap.add_argument("--eager", action="store_true", help="no hipGraph replay")
     ap.add_argument("--keep-head", action="store_true", help="also materialise the fp32 [4+nc][N] head tensor (parity/debug output; the shipped plugin does not)")
+    ap.add_argument("--size", type=int, default=416, help="square model/frame size; 640 = BASELINE configs[3] (then only the headline leg runs)")
     ap.add_argument("--sync-nms", action="store_true", help="run NMS in stream order at the end of every step instead of beside the next step's first kernels")
     ap.add_argument("--dump-ops", default="", help="write the per-op hipEvent profile (name, ms, GFLOP, GB, TFLOP/s, GB/s) to this file")
     a = ap.parse_args()
@@ -194,7 +195,9 @@ def run():
 
     B = a.batch
     big = 64
-    eng = zly.Engine(dtype=zly.DTYPE_BF16, max_batch=max(B, big), max_dets=64, device=local_rank, warmup_runs=3,
+    if a.size != 416:
+        a.no_extras = True
+    eng = zly.Engine(dtype=zly.DTYPE_BF16, model_w=a.size, model_h=a.size, max_batch=max(B, big), max_dets=64, device=local_rank, warmup_runs=3,
                      use_graph=not a.eager, flags=(0 if a.keep_head else zly.FLAG_NO_HEAD_TENSOR) | (0 if a.sync_nms else zly.FLAG_ASYNC_NMS))
     # a real (non-default) torch stream: the engine enqueues on it, and torch.distributed orders the RCCL
     # all-gather of the slabs behind it (with the legacy default stream the engine would fall back to its
@@ -203,7 +206,7 @@ def run():
     torch.cuda.set_stream(stream)
     sp = stream.cuda_stream
     n_sets = 4
-    frames_np = zm.synth_frames(n_sets * big, 416, 416, seed=20250328 + rank, rects=False)
+    frames_np = zm.synth_frames(n_sets * big, a.size, a.size, seed=20250328 + rank, rects=False)
     d_all = torch.from_numpy(frames_np).cuda()
     sets_b = [d_all[i * B:(i + 1) * B] for i in range(n_sets * big // B)][:64]
     sets_1 = [d_all[i:i + 1] for i in range(64)]
@@ -218,14 +221,14 @@ def run():
     log(f"engine ready (rank {rank}/{world}), headline leg: batch {B} x {a.steps} steps")
     # ---- headline: BASELINE config[1] (batch B per GPU per step) -----------------------------------
     gb_head = gather_bufs(B)
-    dt = timed(eng, sets_b, B, a.steps, a.warmup, slab_bufs(B), sp, world, gb_head)
+    dt = timed(eng, sets_b, B, a.steps, a.warmup, slab_bufs(B), sp, world, gb_head, a.size)
     value = world * B * a.steps / dt
     ms_per_step = dt / a.steps * 1e3
     result = {
         "metric": "frames_per_sec", "value": round(value, 1), "unit": "frames/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 5),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"YOLOv8-nano 416x416 batch={B} streaming throughput path, bf16, per MI355X, frames resident in HBM, "
+        "config": {"workload": f"YOLOv8-nano {a.size}x{a.size} batch={B} streaming throughput path, bf16, per MI355X, frames resident in HBM, "
                                f"preprocess+forward+decode+NMS per step" + (", slabs all-gathered over RCCL" if world > 1 else ""),
                    "frames_per_step_per_gpu": B, "global_frames_per_step": world * B, "conf": 0.5, "iou": 0.45,
                    "weights": "seeded synthetic (no real weights offline)", "graph": not a.eager,
