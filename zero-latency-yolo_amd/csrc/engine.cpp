@@ -457,8 +457,8 @@ static bool lanes_active(int n)
     return n >= 16 && !no_lanes;
 }
 
-// Fused bottleneck pair for this op at batch n?  Small launches (few tiles) stay on the per-conv kernels, which
-// split a layer into many more workgroups.  Same answer for both ops of a pair.
+// Fused bottleneck pair for this op at batch n?  Only degenerate launches (a handful of tiles) stay on the per-conv
+// kernels.  Same answer for both ops of a pair.
 static const PairPlan* pair_active(zly_engine* e, const Op& op, int n)
 {
     if (!op.pair || e->dtype != ZLY_DTYPE_BF16 || (e->cfg.flags & ZLY_FLAG_NO_FUSION)) return nullptr;
@@ -468,7 +468,7 @@ static const PairPlan* pair_active(zly_engine* e, const Op& op, int n)
     if (it == e->pair_plans.end()) {
         PairPlan pl{};
         const char* mt = getenv("ZLY_PAIR_MIN_TILES");                 // tuning / tests: force the fused kernel onto small launches
-        const int min_tiles = mt ? atoi(mt) : 192;
+        const int min_tiles = mt ? atoi(mt) : 32;                       // batch 1 (91 / 234 tiles): one fused launch beats two per-conv launches, 4370 -> 4475 fps
         const char* pw = getenv("ZLY_PAIR_WIDTHS");                   // bit mask of fused widths (16 | 32), default both
         const int widths = pw ? atoi(pw) : 48;
         const bool ok = (widths & op.pair_c) && pair_plan(op.pair_c, n, b.H, b.W, &pl) && pl.total_tiles >= min_tiles;
