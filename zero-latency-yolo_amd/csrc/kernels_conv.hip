@@ -418,6 +418,11 @@ static conv_stream_fn pick_stream(int ct, int pt, int nk)
 #ifndef ZLY_TAPS_DEPTH
 #define ZLY_TAPS_DEPTH 1
 #endif
+#ifndef ZLY_LDS_DEPTH
+#define ZLY_LDS_DEPTH 1          // items of global loads in flight ahead of the one being computed.  2 (a second register set,
+                                 // +48..60 VGPRs) was needed while the kernel ran one workgroup per CU; with two or three resident
+                                 // workgroups covering each other it measures the same (tools/diag_lds.hip, -DZLY_LDS_DEPTH=2)
+#endif
 #ifndef ZLY_TAPS_PIN
 #define ZLY_TAPS_PIN 1
 #endif
@@ -631,9 +636,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const ConvArgs a, i
     if (t0 >= total_tiles) return;
     int t1 = t0, c1 = c0; advance(t1, c1);       // next item
     int t2 = t1, c2 = c1; advance(t2, c2);       // the one after
+#if ZLY_LDS_DEPTH == 1
+    u32x4 rpA[NPU_T], rwA[NWU_T];
+    stage_load(t0, c0, rpA, rwA);
+#else
     u32x4 rpA[NPU_T], rwA[NWU_T], rpB[NPU_T], rwB[NWU_T];
     stage_load(t0, c0, rpA, rwA);
     if (t1 < total_tiles) stage_load(t1, c1, rpB, rwB);
+#endif
 #ifdef ZLY_DIAG
     // diagnostic build only (tools/diag_lds.hip): per-wave cycle sums of the phases of an item, written to the
     // buffer passed in a.in2 (unused by 3x3 convs): [store+wait, barrier, load issue, taps+epilogue, barrier, items]
@@ -644,6 +654,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const ConvArgs a, i
 #else
 #define ZPHASE(k) do { } while (0)
 #endif
+#if ZLY_LDS_DEPTH == 1
+    while (true) {
+        stage_store(rpA, rwA);
+        ZPHASE(0);
+        __syncthreads();
+        ZPHASE(1);
+        if (t1 < total_tiles) stage_load(t1, c1, rpA, rwA);
+        ZPHASE(2);
+        compute(t0, c0);
+        ZPHASE(5);
+        __syncthreads();
+        ZPHASE(4);
+#ifdef ZLY_DIAG
+        ++ditems;
+#endif
+        if (t1 >= total_tiles) break;
+        t0 = t1; c0 = c1; advance(t1, c1);
+    }
+#else
     while (true) {
         // ---- item (t0,c0) from set A ----
         stage_store(rpA, rwA);
@@ -679,6 +708,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const ConvArgs a, i
         t0 = t2; c0 = c2; t1 = t3; c1 = c3;
         t2 = t1; c2 = c1; advance(t2, c2);
     }
+#endif
 #ifdef ZLY_DIAG
     if (lane == 0 && a.in2) {
         unsigned long long* o = (unsigned long long*)a.in2 + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 16;
@@ -865,11 +895,22 @@ hipError_t launch_conv(int dtype, const ConvArgs& a, const ConvLaunch& cfg, hipS
         const int n = a.M / (a.Ho * a.Wo);
         const int tiles_per_img = tiles_x * tiles_y, total = tiles_per_img * n;
         int gx = total;
-        const int max_wgs = 2 * 256;                       // two resident workgroups per CU (LDS / VGPR budget)
-        if (gx * ytiles > max_wgs) gx = max_wgs / ytiles;  // never more than are resident: a persistent workgroup
-        if (gx > total) gx = total;                        // that has to wait for a slot runs a whole round alone
         const int nchunks = a.Cin / 32;
         if (cfg.wres && (a.stride != 1 || nchunks > 2)) return hipErrorInvalidValue;
+        if (a.stride < 1 || a.stride > 2 || cfg.ct > 5 || cfg.pt > 4) return hipErrorInvalidValue;
+        // resident workgroups per CU for this variant and LDS size, asked from the runtime once (registers: 94..243 per
+        // lane, LDS 35..80 KB -> 2..4); the persistent grid is exactly what is resident
+        static int occ_cache[3][6][5][3];                  // [stride][ct][pt][wres chunks] -> blocks per CU
+        int& occ = occ_cache[a.stride][cfg.ct][cfg.pt][cfg.wres ? a.Cin / 32 : 0];
+        if (occ == 0) {
+            int o = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, (const void*)fn, 256, lds_bytes(a.stride, cfg.pt, cfg.ct, cfg.wres ? a.Cin / 32 : 1)) != hipSuccess || o < 1) o = 2;
+            occ = o > 4 ? 4 : o;
+        }
+        const char* wv = getenv("ZLY_LDS_WGS_PER_CU");       // tuning aid: force
+        const int max_wgs = (wv ? atoi(wv) : occ) * 256;
+        if (gx * ytiles > max_wgs) gx = max_wgs / ytiles;  // never more than are resident: a persistent workgroup
+        if (gx > total) gx = total;                        // that has to wait for a slot runs a whole round alone
         hipLaunchKernelGGL(fn, dim3(gx, ytiles, 1), dim3(256), lds_bytes(a.stride, cfg.pt, cfg.ct, cfg.wres ? nchunks : 1), s, a, tiles_x, tiles_per_img, total, cfg.wres);
         return hipGetLastError();
     }
