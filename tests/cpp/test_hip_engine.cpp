@@ -2,13 +2,18 @@
 // InferenceEngineManager / IInferenceEngine (reference src/server/main.cpp:224-246,
 // src/network/network_server.cpp:21-22,200-209,243-283), never through the C ABI directly.
 //
-//   test_hip_engine <weights.zlyw> <frames.bin> <out.json>
+//   test_hip_engine <weights.zlyw> <frames.bin> <out.json> [probe | reload <new_weights.zlyw>]
+//
+// reload: after the first pass the model file is replaced by <new_weights.zlyw> (rename over it); the driver waits for the
+// engine's watcher (ZLY_MODEL_WATCH_MS) to pick it up (status model_version 2), submits the same frames again and reports
+// both passes ("results", "results_after_reload") and both status maps.
 //
 // frames.bin: u32 count, then per frame {u16 width, u16 height, u32 nbytes, bytes[nbytes]} (a frame whose
 // nbytes != w*h*3 exercises the INVALID_INPUT path).  Writes one JSON document with the detections
 // every callback delivered, the error behaviour observed, and getStatus(); tests/test_host_engine.py
 // compares it with the ctypes path and the CPU oracle.
 #include "zly_compat.hpp"
+#include "hip_inference_engine.h"
 
 #include <chrono>
 #include <condition_variable>
@@ -141,6 +146,52 @@ int main(int argc, char** argv)
         }
     }
     js << "],";
+    if (argc > 5 && std::string(argv[4]) == "reload") {
+        const std::string hash0 = status["model_hash"];
+        if (std::rename(argv[5], argv[1]) != 0) { std::fprintf(stderr, "rename failed\n"); return 7; }
+        bool swapped = false;
+        for (int i = 0; i < 600 && !swapped; ++i) {                   // up to 30 s
+            std::this_thread::sleep_for(std::chrono::milliseconds(50));
+            swapped = engine->getStatus()["model_version"] == "2";
+        }
+        if (!swapped) { std::fprintf(stderr, "watcher did not reload\n"); return 8; }
+        size_t base;
+        { std::lock_guard<std::mutex> lk(mu); base = got.size(); }
+        for (size_t i = 0; i < frames.size(); ++i) {
+            InferenceRequest r;
+            r.client_id = 2000; r.frame_id = 100 + (uint32_t)i; r.timestamp = 888000 + i;
+            r.width = frames[i].w; r.height = frames[i].h; r.data = frames[i].data;
+            if (engine->submitInference(r).hasError()) return 5;
+        }
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            if (!cv.wait_for(lk, std::chrono::seconds(60), [&] { return got.size() >= base + expected; })) return 6;
+        }
+        auto st2 = engine->getStatus();
+        js << "\"hash_before\":\"" << hash0 << "\",\"status_after_reload\":{";
+        bool f2 = true;
+        for (const auto& kv : st2) { js << (f2 ? "" : ",") << "\"" << kv.first << "\":\"" << kv.second << "\""; f2 = false; }
+        js << "},\"results_after_reload\":[";
+        std::lock_guard<std::mutex> lk(mu);
+        for (size_t i = base; i < got.size(); ++i) {
+            const Got& g = got[i];
+            js << (i > base ? "," : "") << "{\"client_id\":" << g.client_id << ",\"frame_id\":" << g.frame_id << ",\"timestamp\":" << g.timestamp << ",\"dets\":[";
+            for (size_t k = 0; k < g.dets.size(); ++k) {
+                const Detection& d = g.dets[k];
+                uint32_t bits[5];
+                std::memcpy(bits, &d, 20);
+                js << (k ? "," : "") << "[" << bits[0] << "," << bits[1] << "," << bits[2] << "," << bits[3] << "," << bits[4] << ","
+                   << d.class_id << "," << d.track_id << "," << d.timestamp << "]";
+            }
+            js << "]}";
+        }
+        js << "],";
+        // a file that does not load: the old model keeps serving, version unchanged, reloadModel() reports the error
+        { std::ofstream bad(argv[1], std::ios::binary | std::ios::trunc); bad << "not a model"; }
+        auto* hip = dynamic_cast<HipInferenceEngine*>(engine.get());
+        js << "\"reload_bad_file\":" << (hip ? static_cast<int>(hip->reloadModel().error().code) : -1) << ",";
+        js << "\"version_after_bad_file\":\"" << engine->getStatus()["model_version"] << "\",";
+    }
     auto sd = engine->shutdown();
     js << "\"shutdown_ok\":" << (sd.isOk() ? "true" : "false") << ",";
     js << "\"submit_after_shutdown\":" << static_cast<int>(engine->submitInference(probe).error().code) << "}";

@@ -4,6 +4,7 @@
 //          <dir>/frame_roundtrip.pkt  the parsed frame serialised again (must equal frame.pkt byte for byte)
 //          <dir>/report.txt           key=value lines: parsed fields and the error codes of the corrupted variants
 #include "zly_wire.hpp"
+#include "zly_sha256.hpp"
 
 #include <cstdio>
 #include <fstream>
@@ -61,6 +62,12 @@ int main(int argc, char** argv)
         dump(dir + "/dets.pkt", out.value());
         auto back = wire::parseDetectionResult(out.value().data(), out.value().size());
         rep << "dets_parse=" << static_cast<int>(back.error().code) << "\ndets_count=" << (back.isOk() ? back.value().detections.size() : 0) << "\n";
+    }
+    {   // SHA-256 of the model watch (FIPS 180-4 vectors; the file itself as a multi-block input)
+        Sha256 a; a.update("abc", 3); rep << "sha_abc=" << a.hex() << "\n";
+        Sha256 e; rep << "sha_empty=" << e.hex() << "\n";
+        Sha256 m; const char* s56 = "abcdbcdecdefdefgefghfghighijhijkijkljklmklmnlmnomnopnopq"; m.update(s56, 56); rep << "sha_56=" << m.hex() << "\n";
+        rep << "sha_frame_pkt=" << sha256File(dir + "/frame.pkt") << "\nsha_missing=" << sha256File(dir + "/nope") << "\n";
     }
     GameState big;                                                        // 1700 detections * 40 B > 65535: refused, not truncated
     big.detections.resize(1700);

@@ -70,7 +70,8 @@ def test_host_engine_matches_c_abi_and_oracle(tmp_path, weights_path, oracle):
     good = [i for i in range(len(frames)) if i != bad]
     assert [x["frame_id"] for x in res] == good                 # every good frame, once, in submission order
     st = j["status"]
-    for key in ("name", "simulation_mode", "running", "model_path", "queue_size", "inference_count", "inference_errors",
+    for key in ("name", "simulation_mode", "running", "model_path", "model_version", "model_hash", "queue_size", "queue_high_water_mark",
+                "int8_quantization", "zero_copy", "dynamic_batching", "inference_count", "inference_errors",
                 "dropped_frames", "avg_inference_time_ms", "p99_inference_time_ms", "avg_preprocessing_time_ms",
                 "avg_postprocessing_time_ms", "worker_threads"):
         assert key in st, key                                   # reference getStatus keys (onnx_engine.cpp:279-312)
@@ -106,3 +107,54 @@ def test_host_engine_batches_pending_requests(tmp_path, weights_path):
     assert [x["frame_id"] for x in j["results"]] == list(range(24))
     assert int(j["status"]["batches"]) < 24 and j["status"]["inference_count"] == "24"
     assert sum(len(x["dets"]) for x in j["results"]) > 0
+
+
+@pytest.mark.gpu
+def test_host_engine_hot_reload(tmp_path, weights_path):
+    """the model file is watched by SHA-256 (ZLY_MODEL_WATCH_MS=200 here, 10 s as the reference by
+    default) and reloaded when it changes -- new engines are built beside the running ones and swapped in between two
+    batches.  Pass 1 must equal an engine on the old weights, pass 2 an engine on the new ones, byte for byte; a file
+    that does not load leaves the running model serving and the version unchanged."""
+    import hashlib
+    import shutil
+    import zly
+    from oracle_lib import det_fields_equal
+    _ensure_bin()
+    spec = zm.build_spec("n")
+    old_w, new_w, live = tmp_path / "old.zlyw", tmp_path / "new.zlyw", tmp_path / "model.zlyw"
+    shutil.copy(weights_path, old_w)
+    zm.write_zlyw(str(new_w), spec, zm.synth_weights(spec, seed=12345))
+    shutil.copy(old_w, live)
+    new_for_rename = tmp_path / "incoming.zlyw"
+    shutil.copy(new_w, new_for_rename)
+    frames = list(zm.synth_frames(5, 416, 416, seed=23, rects=False))
+    fpath, out = tmp_path / "frames.bin", tmp_path / "out.json"
+    _write_frames(fpath, frames)
+    env = dict(os.environ, ZLY_MAX_BATCH="1", ZLY_MODEL_WATCH_MS="200")
+    r = subprocess.run([BIN, str(live), str(fpath), str(out), "reload", str(new_for_rename)], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr
+    j = json.loads(out.read_text())
+    assert j["status"]["model_version"] == "1" and j["status_after_reload"]["model_version"] == "2"
+    assert j["hash_before"] == hashlib.sha256(old_w.read_bytes()).hexdigest()
+    assert j["status_after_reload"]["model_hash"] == hashlib.sha256(new_w.read_bytes()).hexdigest()
+    assert j["reload_bad_file"] == 202 and j["version_after_bad_file"] == "2"          # MODEL_LOAD_FAILED, old engines keep serving
+    assert [x["frame_id"] for x in j["results_after_reload"]] == [100 + i for i in range(5)]
+
+    def unpack(x):
+        got = np.zeros(len(x["dets"]), dtype=zly.DET_DTYPE)
+        for k, d in enumerate(x["dets"]):
+            bits = np.array(d[:5], dtype=np.uint32).view(np.float32)
+            got[k] = (bits[0], bits[1], bits[2], bits[3], bits[4], d[5], d[6], 0, d[7])
+        return got
+
+    differs = False
+    for path, key in ((old_w, "results"), (new_w, "results_after_reload")):
+        eng = zly.Engine(str(path), max_batch=1, max_dets=256, warmup_runs=1)
+        for x, f in zip(j[key], frames):
+            dets, n = eng.detect(f, cap=256)
+            got = unpack(x)
+            assert len(got) == min(n, 256) and det_fields_equal(got, dets)
+        eng.close()
+    for a_, b_ in zip(j["results"], j["results_after_reload"]):
+        differs = differs or a_["dets"] != b_["dets"]
+    assert differs                                                                        # the two models do not detect the same

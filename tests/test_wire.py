@@ -55,4 +55,10 @@ def test_cpp_wire_matches_oracle(tmp_path):
     got = (tmp_path / "dets.pkt").read_bytes()
     assert got == want and len(got) == 22 + 14 + 3 * 40
     assert rep["dets_serialize"] == "0" and rep["dets_parse"] == "0" and rep["dets_count"] == "3"
+    # SHA-256 of the plugin's model-file watch (host/zly_sha256.hpp; the reference uses OpenSSL, onnx_engine.cpp:1087-1124)
+    import hashlib
+    assert rep["sha_abc"] == "ba7816bf8f01cfea414140de5dae2223b00361a396177a9cb410ff61f20015ad"
+    assert rep["sha_empty"] == "e3b0c44298fc1c149afbf4c8996fb92427ae41e4649b934ca495991b7852b855"
+    assert rep["sha_56"] == "248d6a61d20638b8e5c026930c3e6039a33ce45964ff2167f6ecedd419db06c1"
+    assert rep["sha_frame_pkt"] == hashlib.sha256(pkt).hexdigest() and rep["sha_missing"] == ""
     assert rep["dets_too_big"] == "104"                                                # PACKET_TOO_LARGE instead of a truncated length

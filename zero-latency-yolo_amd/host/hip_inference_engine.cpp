@@ -3,6 +3,7 @@
 #include "hip_inference_engine.h"
 
 #include "zly.h"
+#include "zly_sha256.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -50,36 +51,114 @@ Result<void> HipInferenceEngine::initialize()
     if (running_) return Result<void>::ok();
     const int ndev = std::max(1, envInt("ZLY_NUM_DEVICES", 1));
     const int dev0 = std::max(0, envInt("ZLY_FIRST_DEVICE", 0));
+    first_device_ = dev0;
     for (int d = 0; d < ndev; ++d) {
-        zly_config c;
-        zly_default_config(&c);
-        c.weights_path = config_.model_path.c_str();
-        c.model_w = config_.detection.model_width;
-        c.model_h = config_.detection.model_height;
-        c.conf_thr = config_.confidence_threshold;
-        c.iou_thr = config_.nms_threshold;
-        c.max_batch = max_batch_;
-        c.max_dets = max_dets_;
-        c.device = dev0 + d;
-        c.dtype = envInt("ZLY_FP32", 0) ? ZLY_DTYPE_FP32 : ZLY_DTYPE_BF16;
-        c.warmup_runs = 3;                                   // onnx_engine.cpp:919-954
-        c.use_graph = 1;
-        c.flags = ZLY_FLAG_NO_HEAD_TENSOR;                   // the server only consumes detections
-        zly_engine* e = nullptr;
-        const int32_t rc = zly_create(&c, &e);
-        if (rc != ZLY_OK) {
-            const std::string msg = zly_last_error();
+        int32_t rc = ZLY_OK;
+        std::string msg;
+        zly_engine* e = createEngineOn(dev0 + d, &rc, &msg);
+        if (!e) {
             for (zly_engine* p : engines_) zly_destroy(p);
             engines_.clear();
+            engine_mutex_.clear();
             return Result<void>::error(toErrorCode(rc), "Failed to initialize HIP inference engine: " + msg);
         }
         engines_.push_back(e);
+        engine_mutex_.emplace_back(new std::mutex);
     }
+    {
+        std::lock_guard<std::mutex> lk(stats_mutex_);
+        model_hash_ = sha256File(config_.model_path);
+    }
+    model_version_ = 1;
     running_ = true;
     next_seq_ = 0;
     next_emit_ = 0;
     for (int d = 0; d < ndev; ++d) workers_.emplace_back(&HipInferenceEngine::workerLoop, this, d);
+    if (envInt("ZLY_MODEL_WATCH_MS", 10000) > 0) monitor_ = std::thread(&HipInferenceEngine::monitorLoop, this);
     return Result<void>::ok();
+}
+
+zly_engine* HipInferenceEngine::createEngineOn(int device, int32_t* rc, std::string* msg) const
+{
+    zly_config c;
+    zly_default_config(&c);
+    c.weights_path = config_.model_path.c_str();
+    c.model_w = config_.detection.model_width;
+    c.model_h = config_.detection.model_height;
+    c.conf_thr = config_.confidence_threshold;
+    c.iou_thr = config_.nms_threshold;
+    c.max_batch = max_batch_;
+    c.max_dets = max_dets_;
+    c.device = device;
+    c.dtype = envInt("ZLY_FP32", 0) ? ZLY_DTYPE_FP32 : ZLY_DTYPE_BF16;
+    c.warmup_runs = 3;                                   // onnx_engine.cpp:919-954
+    c.use_graph = 1;
+    c.flags = ZLY_FLAG_NO_HEAD_TENSOR;                   // the server only consumes detections
+    zly_engine* e = nullptr;
+    *rc = zly_create(&c, &e);
+    if (*rc != ZLY_OK) { *msg = zly_last_error(); return nullptr; }
+    return e;
+}
+
+// Build the new engines first (hundreds of milliseconds: weight repack, upload, warm-up, beside the running ones), then
+// swap each one in while its worker is between two batches.  Any failure leaves the running model untouched.
+Result<void> HipInferenceEngine::reloadModel()
+{
+    if (!running_) return Result<void>::error(ErrorCode::NOT_INITIALIZED, "Engine not running");
+    std::lock_guard<std::mutex> rl(reload_mutex_);
+    const std::string hash = sha256File(config_.model_path);
+    std::vector<zly_engine*> fresh;
+    for (size_t d = 0; d < engines_.size(); ++d) {
+        int32_t rc = ZLY_OK;
+        std::string msg;
+        zly_engine* e = createEngineOn(first_device_ + (int)d, &rc, &msg);
+        if (!e) {
+            for (zly_engine* p : fresh) zly_destroy(p);
+            return Result<void>::error(toErrorCode(rc), "Failed to reload model: " + msg);
+        }
+        fresh.push_back(e);
+    }
+    for (size_t d = 0; d < engines_.size(); ++d) {
+        zly_engine* old = nullptr;
+        {
+            std::lock_guard<std::mutex> el(*engine_mutex_[d]);
+            old = engines_[d];
+            engines_[d] = fresh[d];
+        }
+        zly_destroy(old);
+    }
+    {
+        std::lock_guard<std::mutex> lk(stats_mutex_);
+        model_hash_ = hash;
+    }
+    model_version_++;
+    return Result<void>::ok();
+}
+
+void HipInferenceEngine::monitorLoop()
+{
+    const int period_ms = std::max(50, envInt("ZLY_MODEL_WATCH_MS", 10000));
+    int waited = 0;
+    while (running_) {
+        std::this_thread::sleep_for(std::chrono::milliseconds(50));
+        waited += 50;
+        if (waited < period_ms) continue;
+        waited = 0;
+        const std::string now = sha256File(config_.model_path);
+        if (now.empty()) continue;                              // file missing: keep serving (onnx_engine.cpp:484-488)
+        std::string last;
+        {
+            std::lock_guard<std::mutex> lk(stats_mutex_);
+            last = model_hash_;
+        }
+        if (now != last) {
+            auto r = reloadModel();
+            if (r.hasError()) {                                 // remember the bad file so it is not retried every period
+                std::lock_guard<std::mutex> lk(stats_mutex_);
+                model_hash_ = now;
+            }
+        }
+    }
 }
 
 Result<void> HipInferenceEngine::shutdown()
@@ -94,8 +173,10 @@ Result<void> HipInferenceEngine::shutdown()
     for (std::thread& t : workers_)
         if (t.joinable()) t.join();
     workers_.clear();
+    if (monitor_.joinable()) monitor_.join();
     for (zly_engine* e : engines_) zly_destroy(e);
     engines_.clear();
+    engine_mutex_.clear();
     {
         std::lock_guard<std::mutex> lk(queue_mutex_);
         dropped_frames_ += queue_.size();
@@ -132,7 +213,6 @@ std::string HipInferenceEngine::getName() const { return "hip"; }
 
 void HipInferenceEngine::workerLoop(int worker)
 {
-    zly_engine* eng = engines_[(size_t)worker];
     std::vector<Pending> batch;
     std::vector<const uint8_t*> ptrs;
     std::vector<size_t> nbytes;
@@ -172,7 +252,11 @@ void HipInferenceEngine::workerLoop(int worker)
                 const InferenceRequest& r = batch[(size_t)good[(size_t)k]].request;
                 ptrs[(size_t)k] = r.data.data(); nbytes[(size_t)k] = r.data.size(); ws[(size_t)k] = r.width; hs[(size_t)k] = r.height;
             }
-            const int32_t rc = zly_detect_batch(eng, m, ptrs.data(), nbytes.data(), ws.data(), hs.data(), dets.data(), max_dets_, n_out.data());
+            int32_t rc;
+            {
+                std::lock_guard<std::mutex> el(*engine_mutex_[(size_t)worker]);      // a reload swaps the handle between two batches
+                rc = zly_detect_batch(engines_[(size_t)worker], m, ptrs.data(), nbytes.data(), ws.data(), hs.data(), dets.data(), max_dets_, n_out.data());
+            }
             batches_++;
             const uint64_t done_ms = wallMs();
             for (int k = 0; k < m; ++k) {
@@ -223,6 +307,10 @@ std::unordered_map<std::string, std::string> HipInferenceEngine::getStatus() con
     s["simulation_mode"] = "false";
     s["running"] = running_ ? "true" : "false";
     s["model_path"] = config_.model_path;
+    s["model_version"] = std::to_string(model_version_.load());
+    { std::lock_guard<std::mutex> lk(stats_mutex_); s["model_hash"] = model_hash_; }
+    s["int8_quantization"] = "disabled";
+    s["zero_copy"] = "disabled";
     s["queue_size"] = std::to_string(getQueueSize());
     s["queue_high_water_mark"] = std::to_string(queue_high_water_mark_.load());
     s["inference_count"] = std::to_string(inference_count_.load());
@@ -244,7 +332,12 @@ std::unordered_map<std::string, std::string> HipInferenceEngine::getStatus() con
     s["avg_inference_time_ms"] = std::to_string(avg);
     s["p99_inference_time_ms"] = std::to_string(p99);
     zly_stats st{};
-    if (!engines_.empty() && zly_get_stats(engines_[0], &st) == ZLY_OK && st.inference_count > 0) {
+    bool have = false;
+    if (!engines_.empty() && !engine_mutex_.empty()) {
+        std::lock_guard<std::mutex> el(*engine_mutex_[0]);          // the handle may be swapped by a reload
+        have = zly_get_stats(engines_[0], &st) == ZLY_OK;
+    }
+    if (have && st.inference_count > 0) {
         s["avg_preprocessing_time_ms"] = std::to_string(st.total_preprocess_ms / (double)st.inference_count);
         s["avg_postprocessing_time_ms"] = std::to_string(st.total_postprocess_ms / (double)st.inference_count);
     } else {

@@ -12,7 +12,10 @@
 //     copies the request and never blocks on inference (:233-258);
 //   * GameState.frame_id / timestamp echo the request (:520-521); the callback runs on an engine-owned
 //     thread, once per successful frame, and is not invoked for failed frames (:376-388);
-//   * getStatus() exposes the reference's keys (:279-312).
+//   * getStatus() exposes the reference's keys (:279-312);
+//   * the model file is watched (SHA-256 every 10 s, :473-515; ZLY_MODEL_WATCH_MS overrides, 0 = off) and reloaded when it
+//     changes: new engines are built beside the running ones and swapped in between two batches, so no request is
+//     dropped or served by a half-loaded model; a file that fails to load leaves the old model serving (as the reference).
 // Deliberate differences (DESIGN.md "host side"):
 //   * every successful frame reaches the callback, in submission order (the reference drops frames
 //     popped by its worker threads, :459-460);
@@ -47,17 +50,28 @@ public:
     std::string getName() const override;
     std::unordered_map<std::string, std::string> getStatus() const override;
 
+    // hot reload (reference loadModel(path, true) from modelMonitorThreadFunc): also callable directly
+    Result<void> reloadModel();
+
 private:
     struct Pending { uint64_t seq; InferenceRequest request; uint64_t enqueue_ms; };
     struct Done { uint32_t client_id; bool ok; GameState state; };
 
     void workerLoop(int worker);
+    void monitorLoop();
+    zly_engine* createEngineOn(int device, int32_t* rc, std::string* msg) const;
     void emitInOrder(std::vector<std::pair<uint64_t, Done>>&& finished);
 
     ServerConfig config_;
     int max_batch_ = 8;
     int max_dets_ = 256;
     std::vector<zly_engine*> engines_;          // one per GPU
+    std::vector<std::unique_ptr<std::mutex>> engine_mutex_;   // held by a worker for the duration of a batch; by reloadModel to swap
+    int first_device_ = 0;
+    std::thread monitor_;
+    std::mutex reload_mutex_;                   // one reload at a time
+    std::atomic<uint32_t> model_version_{1};
+    std::string model_hash_;                    // guarded by stats_mutex_
     std::vector<std::thread> workers_;
     std::atomic<bool> running_{false};
 
