@@ -1,0 +1,58 @@
+// zly_frame_server.hpp -- the glue NetworkServer provides around the engine, without the socket: packet bytes in ->
+// InferenceRequest -> IInferenceEngine -> game-adapter step -> packet bytes out.  Restates
+// NetworkServer::handleFrameData (reference src/network/network_server.cpp:184-241) and ::onInferenceResult (:243-283)
+// on top of host/zly_wire.hpp and host/zly_game_step.hpp, so that a bytes-in / bytes-out harness around the plugin can
+// be tested end to end.  The transport (ReliableUdp), client registry and event bus of the reference are out of scope.
+#pragma once
+
+#include "zly_game_step.hpp"
+#include "zly_wire.hpp"
+
+#include <atomic>
+#include <chrono>
+
+namespace zero_latency {
+
+class FrameServer {
+  public:
+    using SendFn = std::function<void(uint32_t client_id, const std::vector<uint8_t>& packet)>;
+
+    FrameServer(IInferenceEngine& engine, Cs16DetectionStep& adapter, SendFn send) : engine_(engine), adapter_(adapter), send_(std::move(send))
+    {
+        // NetworkServer's constructor wires the engine callback to onInferenceResult (network_server.cpp:21-22)
+        engine_.setCallback([this](uint32_t client_id, const GameState& state) { onInferenceResult(client_id, state); });
+    }
+
+    // one datagram from `client_id` (the reference resolves the id from the sender address, :88-110)
+    Result<void> onPacket(uint32_t client_id, const uint8_t* data, size_t size)
+    {
+        auto frame = wire::parseFrameData(data, size);
+        if (frame.hasError()) { ++bad_packets_; return Result<void>::error(frame.error()); }
+        auto req = wire::frameToRequest(frame.value(), client_id);
+        if (req.hasError()) { ++bad_packets_; return Result<void>::error(req.error()); }
+        return engine_.submitInference(req.value());
+    }
+
+    uint64_t badPackets() const { return bad_packets_; }
+    uint64_t sentPackets() const { return sent_packets_; }
+
+  private:
+    void onInferenceResult(uint32_t client_id, const GameState& state)
+    {
+        auto processed = adapter_.processDetections(client_id, state, Cs16DetectionStep::kGameCs16);
+        if (processed.hasError()) return;                                  // :266-269: logged and dropped
+        const uint64_t now = (uint64_t)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::system_clock::now().time_since_epoch()).count();
+        auto pkt = wire::serializeDetectionResult(processed.value(), sequence_++, now);
+        if (pkt.hasError()) return;
+        ++sent_packets_;
+        send_(client_id, pkt.value());
+    }
+
+    IInferenceEngine& engine_;
+    Cs16DetectionStep& adapter_;
+    SendFn send_;
+    std::atomic<uint32_t> sequence_{0};
+    std::atomic<uint64_t> bad_packets_{0}, sent_packets_{0};
+};
+
+}  // namespace zero_latency
