@@ -592,6 +592,24 @@ def test_fused_bottleneck_pairs(weights_path, oracle, monkeypatch, w, h, n):
     _assert_bf16_close(h16, hp)
     e.close()
 
+    # 64-channel pairs (26x26 stage): one shared weight buffer, k order (tap, half) instead of the LDS kernel's (half, tap):
+    # same products, other fp32 summation order.  The first such pair sees identical inputs in both engines.
+    monkeypatch.setenv("ZLY_PAIR_WIDTHS", "64")
+    e = zly.Engine(weights_path, model_w=w, model_h=h, max_batch=n, warmup_runs=0)
+    h64 = e.forward(x)
+    with pytest.raises(zly.ZlyError):
+        e.tap("model.6.m.0.cv1", 0)
+    pl = zly.Engine(weights_path, model_w=w, model_h=h, max_batch=n, warmup_runs=0, flags=zly.FLAG_NO_FUSION)
+    pl.forward(x)
+    for i in range(n):
+        g, t = e.tap("model.6.m.0.cv2", i), pl.tap("model.6.m.0.cv2", i)
+        assert np.abs(g - t).max() <= 2.0 ** -6 * np.abs(t).max() and np.mean(g != t) < 0.05, (i, np.abs(g - t).max(), np.mean(g != t))
+    for name in ("model.6.m.1.cv2", "model.12.m.0.cv2", "model.18.m.0.cv2"):
+        g, t = e.tap(name, 0), pl.tap(name, 0)
+        assert g.shape == t.shape and np.isfinite(g).all() and _rms(g - t) <= 0.05 * max(_rms(t), 1e-6), name
+    _assert_bf16_close(h64, hp)
+    e.close(); pl.close()
+
 
 def test_four_class_cs16_head(tmp_path, oracle):
     """The reference's CS 1.6 model has 4 classes (constants.h:35-40): head tensor [1, 8, N].  Class branch = one

@@ -223,14 +223,14 @@ struct PlanBuilder {
     // The two convs just added are a bottleneck's 3x3 pair: when the fused kernel covers this width, the first op
     // also carries the pair kernel's operands (for c = 16 its own weight tiling: one tap per 16x16x16 MFMA k-step).
     bool mark_pair(const std::string& m, int c, bool shortcut) {
-        if (e->dtype != ZLY_DTYPE_BF16 || (c != 16 && c != 32) || e->ops.size() < 2) return true;
+        if (e->dtype != ZLY_DTYPE_BF16 || (c != 16 && c != 32 && c != 64) || e->ops.size() < 2) return true;
         Op& B = e->ops[e->ops.size() - 1];
         Op& A = e->ops[e->ops.size() - 2];
         if (A.ks != 3 || B.ks != 3 || A.stride != 1 || B.stride != 1 || !A.act || !B.act || A.cout != c || B.cout != c) return true;
         if (A.in.co % 8 || B.out.co % 8 || e->bufs[(size_t)A.in.buf].C % 8 || e->bufs[(size_t)B.out.buf].C % 8) return true;
         A.pair = 1; B.pair = 2; A.pair_c = B.pair_c = c; A.pair_res = shortcut ? 1 : 0;
         A.pair_out = B.out;
-        if (c == 32) { A.pair_wA = A.w_off; A.pair_bA = A.b_off; A.pair_wB = B.w_off; A.pair_bB = B.b_off; return true; }
+        if (c >= 32) { A.pair_wA = A.w_off; A.pair_bA = A.b_off; A.pair_wB = B.w_off; A.pair_bB = B.b_off; return true; }
         const char* names[2] = {".cv1", ".cv2"};
         size_t* wo[2] = {&A.pair_wA, &A.pair_wB};
         size_t* bo[2] = {&A.pair_bA, &A.pair_bB};
@@ -469,8 +469,8 @@ static const PairPlan* pair_active(zly_engine* e, const Op& op, int n)
         PairPlan pl{};
         const char* mt = getenv("ZLY_PAIR_MIN_TILES");                 // tuning / tests: force the fused kernel onto small launches
         const int min_tiles = mt ? atoi(mt) : 32;                       // batch 1 (91 / 234 tiles): one fused launch beats two per-conv launches, 4370 -> 4475 fps
-        const char* pw = getenv("ZLY_PAIR_WIDTHS");                   // bit mask of fused widths (16 | 32), default both
-        const int widths = pw ? atoi(pw) : 48;
+        const char* pw = getenv("ZLY_PAIR_WIDTHS");                   // bit mask of fused widths (16 | 32 | 64), default 16 | 32
+        const int widths = pw ? atoi(pw) : 48;                          // 64: built and tested, but no faster than two launches (below)
         const bool ok = (widths & op.pair_c) && pair_plan(op.pair_c, n, b.H, b.W, &pl) && pl.total_tiles >= min_tiles;
         it = e->pair_plans.emplace(key, std::make_pair(ok, pl)).first;
     }

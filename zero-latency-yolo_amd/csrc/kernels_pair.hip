@@ -29,12 +29,25 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 
 template <int C> struct PairGeom;
 template <> struct PairGeom<16> {
-    static constexpr int CT = 1, FRAGB = 8, PITCH = 48, WTILE = 512;
+    static constexpr int CT = 1, KS = 1, FRAGB = 8, PITCH = 48, WTILE = 512;
+    static constexpr bool WRES = true;
     typedef s16x4 frag;
     static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0); }
 };
 template <> struct PairGeom<32> {
-    static constexpr int CT = 2, FRAGB = 16, PITCH = 96, WTILE = 1024;
+    static constexpr int CT = 2, KS = 1, FRAGB = 16, PITCH = 96, WTILE = 1024;
+    static constexpr bool WRES = true;
+    typedef bf16x8 frag;
+    static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+// C = 64 (the 26x26 stage at 416x416): two k-steps per tap, pixel pitch 160 B (conflict-free for 128-byte pixels), and ONE
+// 72 KB weight buffer that holds conv A's weights, then conv B's (both do not fit next to the patches): the kernel is
+// about launches here -- two ~9 us launches become one.  Measured at batch 64: 18.5 us fused vs 2 x 9 us (one tile per CU,
+// so the patch load and both 72 KB weight loads are exposed back to back); batch 1: +0.5 %.  Off by default
+// (ZLY_PAIR_WIDTHS=112 enables it); prefetching conv B's weights during conv A is the obvious next step.
+template <> struct PairGeom<64> {
+    static constexpr int CT = 4, KS = 2, FRAGB = 16, PITCH = 160, WTILE = 1024;
+    static constexpr bool WRES = false;
     typedef bf16x8 frag;
     static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 };
@@ -56,11 +69,14 @@ __device__ __forceinline__ void pair_taps(const unsigned char* __restrict__ src,
         const unsigned char* row = src + off + ky * rowb;
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
-            const F x = *reinterpret_cast<const F*>(row + kx * G::PITCH);
 #pragma unroll
-            for (int c = 0; c < G::CT; ++c) {
-                const F w = *reinterpret_cast<const F*>(wl + (c * 9 + ky * 3 + kx) * G::WTILE);
-                acc[c] = G::mma(w, x, acc[c]);
+            for (int ks = 0; ks < G::KS; ++ks) {
+                const F x = *reinterpret_cast<const F*>(row + kx * G::PITCH + ks * 64);
+#pragma unroll
+                for (int c = 0; c < G::CT; ++c) {
+                    const F w = *reinterpret_cast<const F*>(wl + ((c * 9 + ky * 3 + kx) * G::KS + ks) * G::WTILE);
+                    acc[c] = G::mma(w, x, acc[c]);
+                }
             }
         }
     }
@@ -72,11 +88,12 @@ __global__ __launch_bounds__(NW * 64) void bottleneck_pair_kernel(const PairArgs
     typedef PairGeom<C> G;
     constexpr int NT = NW * 64;
     constexpr int UPP = C / 8;                        // 16-byte units per pixel
-    constexpr int WBYTES = 9 * G::CT * G::WTILE;      // one conv's weights
+    constexpr int WBYTES = 9 * G::KS * G::CT * G::WTILE;   // one conv's weights
+    constexpr int WBUFS = G::WRES ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* lwA = smem;
-    unsigned char* lwB = smem + WBYTES;
-    unsigned char* lin = smem + 2 * WBYTES;
+    unsigned char* lwB = smem + (WBUFS - 1) * WBYTES;
+    unsigned char* lin = smem + WBUFS * WBYTES;
     const int PW = a.TW + 4, PH = a.TH + 4, MW = a.TW + 2, MH = a.TH + 2;
     unsigned char* lmid = lin + (PH * PW * G::PITCH + 15) / 16 * 16;
 
@@ -86,17 +103,19 @@ __global__ __launch_bounds__(NW * 64) void bottleneck_pair_kernel(const PairArgs
     const bf16_t* __restrict__ in = static_cast<const bf16_t*>(a.in) + a.in_co;
     bf16_t* __restrict__ out = static_cast<bf16_t*>(a.out) + a.out_co;
 
-    // weights of both convs -> LDS, once
-    for (int u = tid; u < 2 * WBYTES / 16; u += NT) {
-        const int which = u >= WBYTES / 16;
-        const int v = u - which * (WBYTES / 16);
-        *reinterpret_cast<u32x4_t*>(smem + (size_t)u * 16) = *reinterpret_cast<const u32x4_t*>(static_cast<const unsigned char*>(which ? a.wB : a.wA) + (size_t)v * 16);
+    auto stage_weights = [&](unsigned char* dst, const void* src) {
+        for (int u = tid; u < WBYTES / 16; u += NT)
+            *reinterpret_cast<u32x4_t*>(dst + (size_t)u * 16) = *reinterpret_cast<const u32x4_t*>(static_cast<const unsigned char*>(src) + (size_t)u * 16);
+    };
+    if (G::WRES) {                                     // weights of both convs -> LDS, once
+        stage_weights(lwA, a.wA);
+        stage_weights(lwB, a.wB);
     }
-    // per-lane bias: C = 16 -> channels kq*4..+3; C = 32 (pair-permuted rows) -> tile 0: kq*8..+3, tile 1: kq*8+4..+7
+    // per-lane bias: C = 16 -> channels kq*4..+3; C >= 32 (pair-permuted rows) -> tiles 2j, 2j+1: j*32 + kq*8 .. +3 / +4..+7
     f32x4 biasA[G::CT], biasB[G::CT];
 #pragma unroll
     for (int c = 0; c < G::CT; ++c) {
-        const int ch = C == 16 ? kq * 4 : kq * 8 + c * 4;
+        const int ch = C == 16 ? kq * 4 : (c >> 1) * 32 + kq * 8 + (c & 1) * 4;
         biasA[c] = *reinterpret_cast<const f32x4*>(a.bA + ch);
         biasB[c] = *reinterpret_cast<const f32x4*>(a.bB + ch);
     }
@@ -149,12 +168,16 @@ __global__ __launch_bounds__(NW * 64) void bottleneck_pair_kernel(const PairArgs
         int b, y0, x0;
         tile_origin(tl, b, y0, x0);
         stage_store();
-        __syncthreads();                               // x patch (and, first time, the weights) visible; previous tile's readers done
+        if (!G::WRES) stage_weights(lwA, a.wA);        // conv A's weights into the shared weight buffer
+        __syncthreads();                               // x patch (and the weights) visible; previous tile's readers done
         const int tnext = tl + gridDim.x;
         if (tnext < a.total_tiles) stage_load(tnext);
 
         // ---- conv A: x patch -> intermediate map in LDS -------------------------------------------------------
         for (int t = wave; t < ntA; t += NW) {
+            // C = 64: keep the 72 weight fragments in LDS -- left alone the compiler hoists the loop-invariant reads into
+            // 288 registers (fine for the 18 of C = 32, 295 spills here)
+            if (C == 64) asm volatile("" ::: "memory");
             const int q = t * 16 + p;
             const int qc = min(q, NPA - 1);
             const int my = div_small(qc, invMW), mx = qc - my * MW;
@@ -173,13 +196,21 @@ __global__ __launch_bounds__(NW * 64) void bottleneck_pair_kernel(const PairArgs
             if (q < NPA) {
                 unsigned char* dst = lmid + (my * MW + mx) * G::PITCH;
                 if (C == 16) store4(reinterpret_cast<bf16_t*>(dst) + kq * 4, o[0]);
-                else         store8(reinterpret_cast<bf16_t*>(dst) + kq * 8, o[0], o[G::CT - 1]);
+                else {
+#pragma unroll
+                    for (int g2 = 0; g2 < G::CT / 2; ++g2) store8(reinterpret_cast<bf16_t*>(dst) + g2 * 32 + kq * 8, o[2 * g2], o[(2 * g2 + 1) % G::CT]);
+                }
             }
         }
-        __syncthreads();                               // intermediate map complete
+        __syncthreads();                               // intermediate map complete (and conv A's weights no longer needed)
+        if (!G::WRES) {
+            stage_weights(lwB, a.wB);                  // conv B's weights over conv A's
+            __syncthreads();
+        }
 
         // ---- conv B: intermediate -> output (+ shortcut from the x patch) --------------------------------------
         for (int t = wave; t < ntB; t += NW) {
+            if (C == 64) asm volatile("" ::: "memory");
             const int q = t * 16 + p;
             const int qc = min(q, NPB - 1);
             const int oy = div_small(qc, invTW), ox = qc - oy * a.TW;
@@ -201,12 +232,16 @@ __global__ __launch_bounds__(NW * 64) void bottleneck_pair_kernel(const PairArgs
                     if (a.res) o[0] += load4(reinterpret_cast<const bf16_t*>(xs) + kq * 4);
                     store4(dst + kq * 4, o[0]);
                 } else {
-                    if (a.res) {
-                        f32x4 ra, rb;
-                        load8(reinterpret_cast<const bf16_t*>(xs) + kq * 8, ra, rb);
-                        o[0] += ra; o[G::CT - 1] += rb;
+#pragma unroll
+                    for (int g2 = 0; g2 < G::CT / 2; ++g2) {
+                        f32x4 lo = o[2 * g2], hi = o[(2 * g2 + 1) % G::CT];
+                        if (a.res) {
+                            f32x4 ra, rb;
+                            load8(reinterpret_cast<const bf16_t*>(xs) + g2 * 32 + kq * 8, ra, rb);
+                            lo += ra; hi += rb;
+                        }
+                        store8(dst + g2 * 32 + kq * 8, lo, hi);
                     }
-                    store8(dst + kq * 8, o[0], o[G::CT - 1]);
                 }
             }
         }
@@ -221,29 +256,31 @@ __global__ __launch_bounds__(NW * 64) void bottleneck_pair_kernel(const PairArgs
 // ------------------------------------------------------------------------------------------------
 // waves per workgroup: c = 32 keeps a conv's 18 weight fragments in registers across its pixel-tile loop (the compiler hoists the
 // loop-invariant LDS reads), which needs the 256-VGPR budget of 2 waves per SIMD; c = 16 needs 18 registers for that and runs 16 waves
-static constexpr int PAIR_NW16 = 16, PAIR_NW32 = 8, PAIR_NLD = 4;
+static constexpr int PAIR_NW16 = 16, PAIR_NW32 = 8, PAIR_NW64 = 8, PAIR_NLD = 4, PAIR_NLD64 = 6;
 static int pair_nw(int c) { return c == 16 ? PAIR_NW16 : PAIR_NW32; }
+static int pair_nld(int c) { return c == 64 ? PAIR_NLD64 : PAIR_NLD; }
 static constexpr int PAIR_LDS_MAX = 160 * 1024;
 
-static int pair_pitch(int c) { return c == 16 ? PairGeom<16>::PITCH : PairGeom<32>::PITCH; }
-static int pair_wbytes(int c) { return c == 16 ? 9 * PairGeom<16>::WTILE : 9 * 2 * PairGeom<32>::WTILE; }
+static int pair_pitch(int c) { return c == 16 ? PairGeom<16>::PITCH : c == 32 ? PairGeom<32>::PITCH : PairGeom<64>::PITCH; }
+// LDS bytes of the weight buffer(s): both convs resident for c = 16 / 32, one shared buffer for c = 64
+static int pair_wbytes_total(int c) { return c == 16 ? 2 * 9 * PairGeom<16>::WTILE : c == 32 ? 2 * 9 * 2 * PairGeom<32>::WTILE : 9 * 2 * 4 * PairGeom<64>::WTILE; }
 static size_t pair_lds_bytes(int c, int th, int tw)
 {
     const size_t pitch = (size_t)pair_pitch(c);
-    return 2 * (size_t)pair_wbytes(c) + ((size_t)(th + 4) * (tw + 4) * pitch + 15) / 16 * 16 + (size_t)(th + 2) * (tw + 2) * pitch;
+    return (size_t)pair_wbytes_total(c) + ((size_t)(th + 4) * (tw + 4) * pitch + 15) / 16 * 16 + (size_t)(th + 2) * (tw + 2) * pitch;
 }
 
 // Tile shape for an H x W map and n frames: minimise (rounds of tiles over the 256 CUs) x (16-pixel tile rounds of the
 // two convs over the workgroup's waves + a fixed per-tile cost), subject to the LDS budget and the staging registers.
 bool pair_plan(int c, int n, int H, int W, PairPlan* plan)
 {
-    if (c != 16 && c != 32) return false;
+    if (c != 16 && c != 32 && c != 64) return false;
     const int ncu = 256, nw = pair_nw(c);
     double best = 1e30;
     for (int th = 4; th <= 32; ++th) {
         for (int tw = 8; tw <= 64; ++tw) {
             if (pair_lds_bytes(c, th, tw) > (size_t)PAIR_LDS_MAX) continue;
-            if ((th + 4) * (tw + 4) * (c / 8) > nw * 64 * PAIR_NLD) continue;
+            if ((th + 4) * (tw + 4) * (c / 8) > nw * 64 * pair_nld(c)) continue;
             const int tx = (W + tw - 1) / tw, ty = (H + th - 1) / th;
             const long tiles = (long)n * tx * ty;
             const long rounds = (tiles + ncu - 1) / ncu;
@@ -263,15 +300,18 @@ hipError_t pair_init()
 {
     hipError_t r = hipFuncSetAttribute((const void*)bottleneck_pair_kernel<16, PAIR_NW16, PAIR_NLD>, hipFuncAttributeMaxDynamicSharedMemorySize, PAIR_LDS_MAX);
     if (r != hipSuccess) return r;
-    return hipFuncSetAttribute((const void*)bottleneck_pair_kernel<32, PAIR_NW32, PAIR_NLD>, hipFuncAttributeMaxDynamicSharedMemorySize, PAIR_LDS_MAX);
+    r = hipFuncSetAttribute((const void*)bottleneck_pair_kernel<32, PAIR_NW32, PAIR_NLD>, hipFuncAttributeMaxDynamicSharedMemorySize, PAIR_LDS_MAX);
+    if (r != hipSuccess) return r;
+    return hipFuncSetAttribute((const void*)bottleneck_pair_kernel<64, PAIR_NW64, PAIR_NLD64>, hipFuncAttributeMaxDynamicSharedMemorySize, PAIR_LDS_MAX);
 }
 
 hipError_t launch_pair(int c, const PairArgs& a, const PairPlan& plan, hipStream_t s)
 {
-    if ((c != 16 && c != 32) || a.TH != plan.th || a.TW != plan.tw || plan.grid < 1) return hipErrorInvalidValue;
+    if ((c != 16 && c != 32 && c != 64) || a.TH != plan.th || a.TW != plan.tw || plan.grid < 1) return hipErrorInvalidValue;
     if (a.in_cs % 8 || a.in_co % 8 || a.out_cs % 8 || a.out_co % 8) return hipErrorInvalidValue;       // 16-byte channel groups
     if (c == 16) hipLaunchKernelGGL((bottleneck_pair_kernel<16, PAIR_NW16, PAIR_NLD>), dim3((unsigned)plan.grid), dim3(PAIR_NW16 * 64), (size_t)plan.lds_bytes, s, a);
-    else         hipLaunchKernelGGL((bottleneck_pair_kernel<32, PAIR_NW32, PAIR_NLD>), dim3((unsigned)plan.grid), dim3(PAIR_NW32 * 64), (size_t)plan.lds_bytes, s, a);
+    else if (c == 32) hipLaunchKernelGGL((bottleneck_pair_kernel<32, PAIR_NW32, PAIR_NLD>), dim3((unsigned)plan.grid), dim3(PAIR_NW32 * 64), (size_t)plan.lds_bytes, s, a);
+    else         hipLaunchKernelGGL((bottleneck_pair_kernel<64, PAIR_NW64, PAIR_NLD64>), dim3((unsigned)plan.grid), dim3(PAIR_NW64 * 64), (size_t)plan.lds_bytes, s, a);
     return hipGetLastError();
 }
 
