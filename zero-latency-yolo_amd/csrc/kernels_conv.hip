@@ -868,8 +868,10 @@ void conv_pick_direct(int dtype, int ks, int cin, int cout_pad, int M, ConvLaunc
     const long wgs_pt4 = ((long)(M + 255) / 256) * ytiles;
     const long wgs_pt2 = ((long)(M + 127) / 128) * ytiles;
     const long wgs_pt1 = ((long)(M + 63) / 64) * ytiles;
-    if (wgs_pt4 >= 1024 && cfg->ct <= 4) { cfg->pt = 4; return; }       // CT=5 x PT=4 would need > 200 VGPRs
-    if (wgs_pt2 >= 1024) { cfg->pt = 2; return; }
+    const char* e4 = getenv("ZLY_DIRECT_PT4_MIN");                       // tuning aids
+    const char* e2 = getenv("ZLY_DIRECT_PT2_MIN");
+    if (wgs_pt4 >= (e4 ? atol(e4) : 1024) && cfg->ct <= 4) { cfg->pt = 4; return; }       // CT=5 x PT=4 would need > 200 VGPRs
+    if (wgs_pt2 >= (e2 ? atol(e2) : 256)) { cfg->pt = 2; return; }                      // 1024 before: the K-heavy 1x1 layers at 26x26 re-read their weights per 16 pixels (+0.8 %)
     cfg->pt = 1;
     const int nk = (ks * ks * cin + kstep - 1) / kstep;
     if (wgs_pt1 >= 512 || nk < 4) return;
