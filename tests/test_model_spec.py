@@ -50,3 +50,15 @@ def test_oracle_forward_contract(ref_fp32, ref_bf16):
     assert torch.allclose(y0, y[:1], atol=1e-4)
     yb = ref_bf16.forward(x)
     assert float((yb[:, 4:] - y[:, 4:]).abs().max()) < 0.2
+
+
+def test_stem_pixel_scale_needs_no_divide():
+    """kernels_stem.hip normalises with one multiply: bf16(u8 * (1/255)) must equal bf16(u8 / 255) (reference
+    onnx_engine.cpp:693 + the engine's bf16 rounding) for every byte value; in fp32 the two differ for 126 of them."""
+    import numpy as np
+    import torch
+    i = np.arange(256, dtype=np.float32)
+    div = (i / np.float32(255.0)).astype(np.float32)
+    mul = (i * np.float32(1.0 / 255.0)).astype(np.float32)
+    assert (div != mul).sum() > 100
+    assert torch.equal(torch.from_numpy(div).to(torch.bfloat16), torch.from_numpy(mul).to(torch.bfloat16))
