@@ -48,6 +48,7 @@ __global__ __launch_bounds__(256) void stem_fused_kernel(const StemArgs a)
     const float scale_h = (float)d.h / (float)a.th;
     const uint8_t* src = a.src + d.src_off;
     const bool same = d.w == a.tw && d.h == a.th;
+    const size_t frame_bytes = (size_t)d.w * d.h * 3;
     for (int u = tid; u < STEM_PH * STEM_PW; u += 256) {
         const int py = u / STEM_PW, px = u - py * STEM_PW;
         const int iy = iy0 + py, ix = ix0 + px;
@@ -58,11 +59,17 @@ __global__ __launch_bounds__(256) void stem_fused_kernel(const StemArgs a)
                 sy = (int)((float)iy * scale_h); if (sy > d.h - 1) sy = d.h - 1;
                 sx = (int)((float)ix * scale_w); if (sx > d.w - 1) sx = d.w - 1;
             }
-            const uint8_t* q = src + ((size_t)sy * d.w + sx) * 3;
+            const size_t off = ((size_t)sy * d.w + sx) * 3;
+            const uint8_t* q = src + off;
+            // one (unaligned) 4-byte load instead of three byte loads -- this kernel is bound by instruction issue; the very
+            // last pixel of a frame would read one byte past it and keeps the byte loads
+            unsigned int px4;
+            if (off + 4 <= frame_bytes) __builtin_memcpy(&px4, q, 4);                        // B | G<<8 | R<<16 | next B<<24 (amdhsa: unaligned global access is enabled)
+            else px4 = (unsigned int)q[0] | ((unsigned int)q[1] << 8) | ((unsigned int)q[2] << 16);
             // BGR -> RGB; bf16(u8 * (1/255.f)) == bf16(u8 / 255.f) for all 256 values (tests/test_model_spec.py), so the
             // reference's divide (:693) + the bf16 rounding is one v_cvt_f32_ubyte + v_mul + convert, no table
             const float k = 1.0f / 255.0f;
-            v[0] = (bf16_t)((float)q[2] * k); v[1] = (bf16_t)((float)q[1] * k); v[2] = (bf16_t)((float)q[0] * k);
+            v[0] = (bf16_t)((float)((px4 >> 16) & 0xffu) * k); v[1] = (bf16_t)((float)((px4 >> 8) & 0xffu) * k); v[2] = (bf16_t)((float)(px4 & 0xffu) * k);
         }
         patch[u] = v;
     }
