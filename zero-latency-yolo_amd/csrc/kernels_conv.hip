@@ -285,6 +285,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
     }
 
     // epilogue (see epilogue_px): per pixel tile, all CT channel tiles of this lane at once
+    __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (unsigned)((size_t)a.M * a.out_cs * (a.out_f32 ? 4 : sizeof(T))), 0x00020000);
+    __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.res ? a.res : a.out), 0,
+                                                                    (unsigned)((size_t)a.M * (a.res ? a.res_cs : a.out_cs) * sizeof(T)), 0x00020000);
 #pragma unroll
     for (int t = 0; t < PT; ++t) {
         const int m = m_base + t * 16 + p;
@@ -292,6 +295,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
         f32x4 v[CT];
 #pragma unroll
         for (int c = 0; c < CT; ++c) v[c] = acc[c][t];
+        if constexpr (sizeof(T) == 2) {
+            if (!a.out_f32) { epilogue_px_buf<CT>(a, rout, rres, v, biasr, blockIdx.y * CT, kq, m); continue; }     // bf16 NHWC output: 32-bit buffer offsets
+        }
         epilogue_px<T, CT>(a, v, biasr, blockIdx.y * CT, kq, m);
     }
 }
