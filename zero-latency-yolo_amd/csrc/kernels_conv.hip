@@ -424,6 +424,9 @@ static conv_stream_fn pick_stream(int ct, int pt, int nk)
 #ifndef ZLY_TAPS_DEPTH
 #define ZLY_TAPS_DEPTH 1
 #endif
+#ifndef ZLY_LDS_MIN_WAVES
+#define ZLY_LDS_MIN_WAVES 2      // waves per SIMD the register allocation must allow (= resident workgroups per CU of this 4-wave kernel)
+#endif
 #ifndef ZLY_LDS_DEPTH
 #define ZLY_LDS_DEPTH 1          // items of global loads in flight ahead of the one being computed.  2 (a second register set,
                                  // +48..60 VGPRs) was needed while the kernel ran one workgroup per CU; with two or three resident
@@ -490,7 +493,7 @@ template <int S, int PT> struct LdsGeom {
 };
 
 template <int S, int CT, int PT>
-__global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const ConvArgs a, int tiles_x, int tiles_per_img, int total_tiles, int wres)
+__global__ __launch_bounds__(256, ZLY_LDS_MIN_WAVES) void conv3x3_lds_kernel(const ConvArgs a, int tiles_x, int tiles_per_img, int total_tiles, int wres)
 {
     typedef LdsGeom<S, PT> G;
     constexpr int PW = G::PW, PITCH = G::PITCH;

@@ -77,7 +77,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("ZLY_LIB") or LIB_PATH          # ZLY_LIB: A/B two builds on one box (dev aid)
     if not os.path.exists(p):
         raise FileNotFoundError(f"{p} not found: build the HIP extension first (make, or __graft_entry__.build())")
     lib = C.CDLL(p)
