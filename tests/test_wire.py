@@ -62,3 +62,16 @@ def test_cpp_wire_matches_oracle(tmp_path):
     assert rep["sha_56"] == "248d6a61d20638b8e5c026930c3e6039a33ce45964ff2167f6ecedd419db06c1"
     assert rep["sha_frame_pkt"] == hashlib.sha256(pkt).hexdigest() and rep["sha_missing"] == ""
     assert rep["dets_too_big"] == "104"                                                # PACKET_TOO_LARGE instead of a truncated length
+
+
+def test_wire_oracle_matches_committed_vectors():
+    """tests/golden/wire_golden.json (made by tests/golden/make_wire_golden.py) pins the Python restatement itself."""
+    import importlib.util
+    import json
+    g = os.path.join(ROOT, "tests", "golden")
+    spec = importlib.util.spec_from_file_location("make_wire_golden", os.path.join(g, "make_wire_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    want = json.load(open(os.path.join(g, "wire_golden.json")))
+    assert mod.vectors() == want
+    assert want["crc16_123456789"] == 0x29B1 and len(bytes.fromhex(want["empty_heartbeat"])) == 22
