@@ -427,6 +427,10 @@ static conv_stream_fn pick_stream(int ct, int pt, int nk)
 #ifndef ZLY_LDS_MIN_WAVES
 #define ZLY_LDS_MIN_WAVES 2      // waves per SIMD the register allocation must allow (= resident workgroups per CU of this 4-wave kernel)
 #endif
+#ifndef ZLY_LDS_WDMA
+#define ZLY_LDS_WDMA 1           // per-item weight tiles go global -> LDS by LDS-DMA (buffer_load ... lds): no register round trip, no ds_write;
+                                 // 186 -> 133 registers for the CT=4 x PT=2 variant (3 resident workgroups per CU), +3 % on the whole step.  0 = through registers
+#endif
 #ifndef ZLY_LDS_DEPTH
 #define ZLY_LDS_DEPTH 1          // items of global loads in flight ahead of the one being computed.  2 (a second register set,
                                  // +48..60 VGPRs) was needed while the kernel ran one workgroup per CU; with two or three resident
@@ -559,7 +563,7 @@ __global__ __launch_bounds__(256, ZLY_LDS_MIN_WAVES) void conv3x3_lds_kernel(con
                 v = *reinterpret_cast<const u32x4*>(inb + usrc[i]);
             rp[i] = v;
         }
-        if (w_once) return;                                   // weights are resident
+        if (w_once || ZLY_LDS_WDMA) return;                   // weights are resident / moved by LDS-DMA
         const bf16_t* wc = wbase + c * 512;
 #pragma unroll
         for (int i = 0; i < NWU_T; ++i) rw[i] = *reinterpret_cast<const u32x4*>(wc + uwsrc[i]);
@@ -570,7 +574,7 @@ __global__ __launch_bounds__(256, ZLY_LDS_MIN_WAVES) void conv3x3_lds_kernel(con
             const int u = tid + i * 256;
             if (u < NPU) *reinterpret_cast<u32x4*>(lpatch + (u >> 2) * PITCH + (u & 3) * 16) = rp[i];
         }
-        if (w_once && w_staged) return;
+        if ((w_once && w_staged) || ZLY_LDS_WDMA) return;
         w_staged = true;
 #pragma unroll
         for (int i = 0; i < NWU_T; ++i) {
@@ -585,6 +589,22 @@ __global__ __launch_bounds__(256, ZLY_LDS_MIN_WAVES) void conv3x3_lds_kernel(con
 #pragma unroll
         for (int t = 0; t < PT; ++t) acc[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+#if ZLY_LDS_WDMA
+    // LDS-DMA of one chunk's weight tiles: tile ti = tap * CT + ct is one contiguous KiB in lane order on both sides; wave w
+    // moves tiles w, w+4, ...; completion is the wave's vmcnt, visibility the workgroup barrier that follows
+    const __amdgpu_buffer_rsrc_t rwgt = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(wbase), 0, (unsigned)(CT * a.nk * 1024), 0x00020000);
+    auto dma_weights = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < (9 * CT + 3) / 4; ++i) {
+            const int ti = wave + 4 * i;
+            if (ti < 9 * CT) {
+                const int t = ti / CT, ct = ti - t * CT;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rwgt, (__attribute__((address_space(3))) void*)(lw + ti * 1024), 16, lane * 16,
+                                                         (ct * a.nk + t * nchunks + c) * 1024, 0, 0);
+            }
+        }
+    };
+#endif
     f32x4 biasr[CT];
     load_bias<CT>(a, blockIdx.y * CT, kq, biasr);
     const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (unsigned)((size_t)a.M * a.out_cs * 2), 0x00020000);
@@ -596,6 +616,8 @@ __global__ __launch_bounds__(256, ZLY_LDS_MIN_WAVES) void conv3x3_lds_kernel(con
 #define ZPHASE(k) do { ZSTAMP(dT1); dsum[k] += dT1 - dT0; dT0 = dT1; } while (0)
 #endif
     // 9 taps of one staged chunk; the epilogue runs after a tile's last chunk
+    bool dma_next_valid = false; int dma_next_c = 0;
+    (void)dma_next_valid; (void)dma_next_c;
     auto compute = [&](int tl, int c) {
 #if ZLY_TAPS_DEPTH > 0
         taps_mma<CT, PT, S, PW, PITCH>(lpatch, w_once ? lw + (size_t)c * (NWU * 16) : lw, lane, wave * PT, p, kq, acc);
@@ -620,6 +642,12 @@ __global__ __launch_bounds__(256, ZLY_LDS_MIN_WAVES) void conv3x3_lds_kernel(con
 #endif
 #ifdef ZLY_DIAG
         ZPHASE(3);
+#endif
+#if ZLY_LDS_WDMA
+        if (!w_once) {
+            __syncthreads();                                   // every wave is done reading this item's weights and patch
+            if (dma_next_valid) dma_weights(dma_next_c);       // the next item's weights land during the epilogue / patch store
+        }
 #endif
         if (c != nchunks - 1) return;
         // epilogue for tile tl (see epilogue_px)
@@ -664,16 +692,27 @@ __global__ __launch_bounds__(256, ZLY_LDS_MIN_WAVES) void conv3x3_lds_kernel(con
 #define ZPHASE(k) do { } while (0)
 #endif
 #if ZLY_LDS_DEPTH == 1
+#if ZLY_LDS_WDMA
+    if (!w_once) dma_weights(c0);
+#endif
     while (true) {
         stage_store(rpA, rwA);
+#if ZLY_LDS_WDMA
+        if (!w_once) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this item's weight DMA (and whatever was issued after it) has landed
+#endif
         ZPHASE(0);
         __syncthreads();
         ZPHASE(1);
         if (t1 < total_tiles) stage_load(t1, c1, rpA, rwA);
         ZPHASE(2);
+        dma_next_valid = t1 < total_tiles; dma_next_c = c1;
         compute(t0, c0);
         ZPHASE(5);
+#if ZLY_LDS_WDMA
+        if (w_once) __syncthreads();                           // (the DMA path has its barrier between the taps and the epilogue)
+#else
         __syncthreads();
+#endif
         ZPHASE(4);
 #ifdef ZLY_DIAG
         ++ditems;
