@@ -848,13 +848,14 @@ static bool pick_lds_config(int stride, int cin, int cout_pad, int n, int Ho, in
     for (int i = 0; i < 4; ++i)
         if (ntiles % pref[i] == 0) { ct = pref[i]; break; }
     if (!ct) return false;
-    // resident weights (stride 1, Cin 32 / 64) when the weights of ALL chunks of the preferred channel block fit beside the
-    // patch with two workgroups per CU (<= 80 KB each): Cin = 32 always, Cin = 64 with CT = 3 (the 144-channel Detect
-    // stems, 54 KB).  Measured (tools/diag_lds.hip): 64 -> 144 at 52x52: 71 -> 63 us; halving CT to make 64 -> 64 resident
-    // (CT = 2 x 2 channel blocks, patch staged twice) was slower than CT = 4 with per-item weights: 37 vs 32 us.
+    // resident weights: Cin = 32 (one chunk: every item of the workgroup uses the same tiles, so they are staged once).  For
+    // Cin = 64 with CT = 3 (the 64 -> 144 Detect stems, 54 KB for both chunks) residency won 12 % while weights went through
+    // registers; since they go by LDS-DMA the per-item copy is cheap and three resident workgroups beat two with resident
+    // weights (ZLY_WRES_MAXCHUNKS=2 restores it).  Halving CT to make 64 -> 64 resident was always slower (37 vs 32 us).
     cfg->wres = 0;
     const char* nr = getenv("ZLY_NO_WRES");
-    if (stride == 1 && cin <= 64 && !nr) {
+    const char* wm = getenv("ZLY_WRES_MAXCHUNKS");                   // tuning aid
+    if (stride == 1 && cin <= 32 * (wm ? atoi(wm) : 1) && !nr) {
         static const int rpref[4] = {4, 3, 2, 5};
         for (int i = 0; i < 4; ++i) {
             const int c = rpref[i];
