@@ -1,0 +1,120 @@
+"""Set-level comparison of two detection lists: the detections of an engine that computes in
+bf16 against the detections of the fp32 oracle, "matched by greedy match (same class, IoU >= 0.9) after excluding oracle
+candidates with |score - 0.5| < band or pairwise |IoU - 0.45| < band (the threshold-flip band)".
+
+Excluding single candidates is not enough once NMS runs: a pair whose IoU sits at the threshold flips one suppression,
+and the box that survives may suppress a third one (a cascade).  Cascades cannot leave a connected component of the
+graph  {nodes: oracle anchors scoring >= conf - band; edges: same class and IoU >= iou_thr - band}, because greedy
+class-aware NMS (reference onnx_engine.cpp:837-878) only ever lets a box act on a same-class box it overlaps by more
+than the threshold, in either of the two runs being compared.  So:
+  * a component is AMBIGUOUS when it holds a node with |score - conf| <= band, an edge with |IoU - iou_thr| <= band, or
+    two overlapping nodes whose scores are within band of each other (their greedy order may swap) and which do not
+    suppress the same third nodes: both outcomes are legitimate there and it is skipped (and counted);
+  * in every other component the two detection sets must be identical: same number, one-to-one matched with the same
+    class, IoU >= min_iou and |confidence difference| <= band;
+  * every detection of the engine must land on an oracle node (same class, IoU >= min_iou): a detection from nowhere
+    is an error whatever the bands.
+TEST INFRASTRUCTURE (imported by tests/ only)."""
+import numpy as np
+
+
+def _iou_matrix(a, b):
+    """IoU of centre-format boxes, a [n][4], b [m][4] (float64; the bands absorb the difference to the fp32 oracle IoU)."""
+    a = np.asarray(a, dtype=np.float64).reshape(-1, 4)
+    b = np.asarray(b, dtype=np.float64).reshape(-1, 4)
+    ax1, ay1, ax2, ay2 = a[:, 0] - a[:, 2] / 2, a[:, 1] - a[:, 3] / 2, a[:, 0] + a[:, 2] / 2, a[:, 1] + a[:, 3] / 2
+    bx1, by1, bx2, by2 = b[:, 0] - b[:, 2] / 2, b[:, 1] - b[:, 3] / 2, b[:, 0] + b[:, 2] / 2, b[:, 1] + b[:, 3] / 2
+    iw = np.clip(np.minimum(ax2[:, None], bx2[None]) - np.maximum(ax1[:, None], bx1[None]), 0, None)
+    ih = np.clip(np.minimum(ay2[:, None], by2[None]) - np.maximum(ay1[:, None], by1[None]), 0, None)
+    inter = iw * ih
+    union = (a[:, 2] * a[:, 3])[:, None] + (b[:, 2] * b[:, 3])[None] - inter
+    return np.where(union > 0, inter / np.where(union > 0, union, 1), 0.0)
+
+
+def _boxes(d):
+    return np.stack([d["x"], d["y"], d["w"], d["h"]], 1).astype(np.float64) if len(d) else np.zeros((0, 4))
+
+
+def compare_detection_sets(oracle, ref_head, got, img_w, img_h, conf=0.5, iou_thr=0.45, band=2e-2, min_iou=0.9):
+    """oracle: tests/oracle_lib.Oracle; ref_head: fp32 oracle head tensor [4+nc][N] of the frame; got: the engine's
+    detections (structured zly_det array).  Returns (n_compared, n_skipped, errors): detections compared exactly,
+    oracle detections skipped inside ambiguous components, list of error strings (empty = parity holds)."""
+    nodes = oracle.decode(ref_head, img_w, img_h, max(conf - band, 1e-6))
+    want = oracle.postprocess(ref_head, img_w, img_h, conf, iou_thr)
+    errors = []
+    nb = _boxes(nodes)
+    n = len(nodes)
+    comp = np.arange(n)
+
+    def find(i):
+        while comp[i] != i:
+            comp[i] = comp[comp[i]]
+            i = comp[i]
+        return i
+
+    amb_node = np.abs(nodes["confidence"].astype(np.float64) - conf) <= band if n else np.zeros(0, bool)
+    amb_edges = []
+    if n:
+        iou = _iou_matrix(nb, nb)
+        same = nodes["class_id"][:, None] == nodes["class_id"][None]
+        ii, jj = np.nonzero(np.triu(same & (iou >= iou_thr - band), 1))
+        for i, j in zip(ii, jj):
+            ri, rj = find(i), find(j)
+            if ri != rj:
+                comp[ri] = rj
+            if abs(iou[i, j] - iou_thr) <= band:
+                amb_edges.append(i)
+            elif abs(float(nodes["confidence"][i]) - float(nodes["confidence"][j])) <= band:
+                # the greedy order of i and j may swap: harmless unless they differ in which same-class boxes they suppress
+                si, sj = same[i] & (iou[i] > iou_thr), same[j] & (iou[j] > iou_thr)
+                diff = si != sj
+                diff[i] = diff[j] = False
+                if diff.any():
+                    amb_edges.append(i)
+    roots = np.array([find(i) for i in range(n)], dtype=np.int64)
+    ambiguous = set(int(roots[i]) for i in np.nonzero(amb_node)[0]) | set(int(roots[i]) for i in amb_edges)
+
+    def locate(dets, what):
+        """component root of every detection (by its best same-class node), -1 = none"""
+        out = np.full(len(dets), -1, dtype=np.int64)
+        if len(dets) == 0 or n == 0:
+            if len(dets):
+                errors.append(f"{len(dets)} {what} detection(s) but the oracle has no candidate at all")
+            return out
+        m = _iou_matrix(_boxes(dets), nb)
+        m = np.where(dets["class_id"][:, None] == nodes["class_id"][None], m, -1.0)
+        best = m.argmax(1)
+        for k in range(len(dets)):
+            if m[k, best[k]] >= min_iou:
+                out[k] = roots[best[k]]
+            else:
+                errors.append(f"{what} detection {k} (class {int(dets['class_id'][k])}, conf {float(dets['confidence'][k]):.4f}) matches no oracle "
+                              f"candidate: best same-class IoU {float(m[k, best[k]]):.3f}")
+        return out
+
+    wc, gc = locate(want, "oracle"), locate(got, "engine")
+    compared = skipped = 0
+    for root in sorted(set(int(r) for r in roots)):
+        wi, gi = np.nonzero(wc == root)[0], np.nonzero(gc == root)[0]
+        if root in ambiguous:
+            skipped += len(wi)
+            continue
+        compared += len(wi)
+        if len(wi) != len(gi):
+            errors.append(f"component {root}: oracle keeps {len(wi)} detection(s), engine {len(gi)}")
+            continue
+        if len(wi) == 0:
+            continue
+        m = _iou_matrix(_boxes(got[gi]), _boxes(want[wi]))
+        used = set()
+        for a in range(len(gi)):
+            order = np.argsort(-m[a])
+            hit = next((b for b in order if b not in used and m[a, b] >= min_iou), None)
+            if hit is None:
+                errors.append(f"component {root}: engine detection {int(gi[a])} has no oracle partner at IoU >= {min_iou} (best {float(m[a].max()):.3f})")
+                continue
+            used.add(hit)
+            dc = abs(float(got["confidence"][gi[a]]) - float(want["confidence"][wi[hit]]))
+            if dc > band:
+                errors.append(f"component {root}: confidence differs by {dc:.4f} > {band}")
+    return compared, skipped, errors

@@ -1,11 +1,18 @@
 """GPU parity tests (run on the MI355X box: pytest -m gpu).  Every call goes through the C ABI of
 libzly.so; the CPU oracle (oracle/) is only the checker.
 
-Tolerances (stated here, used below):
+Tolerances (SURVEY.md section 8c, stated here, used below):
   * preprocess, decode, NMS: BIT-EXACT against oracle/zly_oracle.c (integer / single-rounded fp32 work).
   * fp32 engine head tensor vs fp32 oracle: box rows <= FP32_BOX_TOL px, score rows <= FP32_SCORE_TOL
     (summation-order differences of an exact-fp32 MFMA chain vs MLAS/oneDNN only).
-  * bf16 engine vs the bf16-rounding-emulating oracle: BF16E_* ; vs the plain fp32 oracle: BF16_* .
+  * bf16 engine head tensor, against the fp32 oracle AND the bf16-rounding oracle: box rows <= 1.5 px, score rows <= 2e-2
+    (max over every anchor of every frame), plus rms bounds a few times the measured noise floor of bf16 itself;
+    every conv output of the PRODUCTION kernels within 2^-5 of the tensor's range of the bf16-rounding oracle;
+    detection SETS equal to the fp32 oracle's outside the threshold-flip band (tests/parity_sets.py).
+  The synthetic weights are calibrated so that these bounds mean something (tools/zly_model.py: noise-stable
+  activations, peaked Gaussian DFL): the noise floor of bf16 itself on this model -- bf16-rounding oracle vs fp32
+  oracle, both on the CPU -- is box rms 0.05 px / max 0.5 px, score rms 6e-4 / max 9e-3.  The forward pass is PARITY
+  UNPINNED against the reference (ONNX Runtime + an ultralytics export are not available offline, oracle/yolov8_ref.py).
 """
 import numpy as np
 import pytest
@@ -14,18 +21,16 @@ import torch
 import zly
 import zly_model as zm
 from oracle_lib import det_fields_equal
+from parity_sets import compare_detection_sets
 
 pytestmark = pytest.mark.gpu
 
-FP32_BOX_TOL = 5e-2      # px (values reach ~800 px: 6e-5 relative; measured 1.3e-2)
-FP32_SCORE_TOL = 1e-4    # measured 1.5e-5
-# bf16: the seeded synthetic network has near-uniform DFL softmaxes, so box rows amplify rounding
-# noise (one bin = 8/16/32 px).  The noise FLOOR of bf16 itself on this model -- the bf16-rounding
-# oracle vs the fp32 oracle, both on the CPU -- is box rms 2.3 px / max 50 px, score rms 1.7e-3 /
-# max 0.09 (DESIGN.md "bf16 tolerance").  The engine must stay within these bounds:
-BF16_BOX_RMS, BF16_BOX_MAX = 4.0, 80.0        # px
-BF16_SCORE_RMS, BF16_SCORE_MAX = 4e-3, 0.15
+FP32_BOX_TOL = 1e-3      # px
+FP32_SCORE_TOL = 1e-4
+BF16_BOX_MAX, BF16_SCORE_MAX = 1.5, 2e-2      # px @416 / absolute
+BF16_BOX_RMS, BF16_SCORE_RMS = 0.2, 2e-3      # ~4x the noise floor of bf16 itself on this model
 BF16_FLIP_BAND = BF16_SCORE_MAX                # |score - 0.5| below which a candidate may legitimately flip
+LAYER_MAX, LAYER_RMS = 2.0 ** -5, 0.03         # conv outputs vs the bf16-rounding oracle: max |d| / max |t|, rms(d) / std(t)
 F6 = ["x", "y", "w", "h", "confidence", "class_id"]
 
 
@@ -160,28 +165,132 @@ def _assert_bf16_close(got, want):
     assert _rms(ds) <= BF16_SCORE_RMS and np.abs(ds).max() <= BF16_SCORE_MAX, (_rms(ds), np.abs(ds).max())
 
 
+def _assert_layer_close(g, t, name):
+    """a conv output of the engine against the bf16-rounding oracle's: an indexing / tile-edge bug moves a few elements
+    by O(std) = 10-20 % of the range, bf16 rounding flips move them by < 1.6 % (measured floor, CPU)"""
+    assert g.shape == t.shape, (name, g.shape, t.shape)
+    d = g - t
+    assert np.isfinite(g).all(), name
+    assert np.abs(d).max() <= LAYER_MAX * np.abs(t).max(), (name, float(np.abs(d).max() / np.abs(t).max()))
+    assert _rms(d) <= LAYER_RMS * float(t.std()), (name, _rms(d) / float(t.std()))
+
+
+def _all_conv_names():
+    return [c.name for c in zm.build_spec("n").convs]
+
+
+def _check_taps(eng, ref, frame_ids, skip_ok=()):
+    """every conv output the engine can expose, for the given frames, against the oracle's taps; returns the names checked"""
+    checked = []
+    for name in _all_conv_names():
+        for i in frame_ids:
+            try:
+                g = eng.tap(name, i)
+            except zly.ZlyError as exc:
+                assert any(name.endswith(sfx) for sfx in skip_ok), (name, exc.message)
+                break
+            _assert_layer_close(g, ref.taps[name][i].numpy(), f"{name}[{i}]")
+        else:
+            checked.append(name)
+    return checked
+
+
 def test_forward_bf16_vs_emulating_oracle(eng16, weights_path, oracle, ref_bf16):
-    """bf16 engine vs the oracle that rounds at the same points.  The stem output (identical inputs)
-    must agree to 1 bf16 ulp (2^-7 relative); the next layers -- one per conv kernel mode: 3x3 generic-K,
-    1x1, 3x3 with residual, 3x3 fast-K -- to 2^-5 of the tensor's range, which pins the bf16 MFMA
-    indexing; deeper layers drift chaotically and are bounded by the head tolerance."""
+    """bf16 engine vs the oracle that rounds at the same points (weights and every stored activation to bf16, fp32
+    accumulate, the six final Detect convs in fp32).  The stem output (identical inputs) must agree to 1 bf16 ulp (2^-7
+    relative); EVERY one of the 63 conv outputs to 2^-5 of its range (pins the MFMA indexing of each kernel mode: 3x3
+    generic-K, 3x3 fast-K, 3x3 split-K, 1x1, dual-source 1x1, residual, SPPF concat, the fused Detect tail's logits)."""
     frames = zm.synth_frames(2, 416, 416, seed=6, rects=False)
     x = _pre(oracle, frames)
     want = ref_bf16.forward(torch.from_numpy(x)).numpy()
     got = eng16.forward(x)
     _assert_bf16_close(got, want)
     # per-layer taps from an engine that runs every conv as its own kernel (the fused bottleneck keeps m.0.cv1 in LDS)
-    eng16 = zly.Engine(weights_path, max_batch=2, warmup_runs=0, flags=zly.FLAG_NO_FUSION)
-    got = eng16.forward(x)
-    t, g = ref_bf16.taps["model.0"][1].numpy(), eng16.tap("model.0", 1)
+    e = zly.Engine(weights_path, max_batch=2, warmup_runs=0, flags=zly.FLAG_NO_FUSION | zly.FLAG_DUMP_LOGITS)
+    got = e.forward(x)
+    t, g = ref_bf16.taps["model.0"][1].numpy(), e.tap("model.0", 1)
     assert np.all(np.abs(g - t) <= 2.0 ** -7 * np.abs(t) + 1e-6)      # same inputs: at most 1 ulp apart
     assert np.mean(g != t) < 0.02                                       # and flips are rare, not systematic
-    for name in ("model.1", "model.2.cv1", "model.2.m.0.cv1", "model.2.m.0.cv2", "model.2.cv2", "model.3", "model.4.m.0.cv1"):
-        t = ref_bf16.taps[name][1].numpy()
-        g = eng16.tap(name, 1)
-        assert np.abs(g - t).max() <= 2.0 ** -5 * np.abs(t).max(), name
+    assert len(_check_taps(e, ref_bf16, (0, 1))) == 63
     _assert_bf16_close(got, want)
-    eng16.close()
+    e.close()
+
+
+@pytest.mark.parametrize("w,h", [(800, 600), (1920, 1080), (417, 415), (64, 48), (1, 1), (416, 416)])
+def test_fused_stem_kernel_vs_oracle(eng16, oracle, ref_bf16, w, h):
+    """stem_fused_kernel -- the PRODUCTION preprocess + model.0 of the bf16 engine (kernels_stem.hip) -- has its own
+    nearest-neighbour resize map, BGR->RGB and u8 -> bf16 scaling.  After detect() on a frame of another size, the
+    model.0 tensor it left in HBM must equal conv(preProcess(frame)) of the oracles (reference onnx_engine.cpp:673-693
+    for the map) to 1 bf16 ulp: a resize index off by one moves whole pixels by O(1)."""
+    rng = np.random.default_rng(w * 10007 + h)
+    img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    rc, pre = oracle.preprocess(img, 416, 416)
+    assert rc == 0
+    ref_bf16.forward(torch.from_numpy(pre[None]))
+    t = ref_bf16.taps["model.0"][0].numpy()
+    eng16.detect(img, cap=8)
+    g = eng16.tap("model.0", 0)
+    assert g.shape == t.shape
+    assert np.all(np.abs(g - t) <= 2.0 ** -7 * np.abs(t) + 1e-6), float(np.abs(g - t).max())
+    assert np.mean(g != t) < 0.02
+    # and inside a mixed-size batch (per-frame descriptors), as the last frame
+    other = zm.synth_frames(1, 416, 416, seed=2, rects=False)[0]
+    eng16.detect_batch([other, img], cap=8)
+    g = eng16.tap("model.0", 1)
+    assert np.all(np.abs(g - t) <= 2.0 ** -7 * np.abs(t) + 1e-6) and np.mean(g != t) < 0.02
+
+
+@pytest.mark.parametrize("n", [16, 64])
+def test_production_kernels_layerwise_vs_oracle(weights_path, oracle, ref_fp32, ref_bf16, n):
+    """The kernels the headline number runs, at the batch sizes that select them (conv3x3_lds_kernel S = 1 / 2, resident and
+    per-item weights; conv1x1_stream_kernel in every (CT, PT, NK) shape; bottleneck_pair_kernel; stem_fused_kernel; the
+    dual-source 1x1 convs; Detect branches on the side streams with per-level tail launches; deferred NMS), checked at
+    LAYER level: after one production-path step (zly_detect_device, the flags bench.py uses + the debug dumps) every conv
+    output left in HBM -- 59 of 63: the first conv of a fused bottleneck pair stays in LDS -- must match the bf16-rounding
+    oracle within 2^-5 of its range for the first, a middle and the last frame of the batch; the head tensor of ALL n
+    frames must be within SURVEY 8c's bf16 tolerance of the fp32 oracle, and all n frames' detections must match the
+    fp32 oracle's as sets."""
+    frames = zm.synth_frames(n, 416, 416, seed=77, rects=False)
+    x = torch.from_numpy(_pre(oracle, frames))
+    want16 = ref_bf16.forward(x).numpy()
+    want32 = ref_fp32.forward(x).numpy()
+    e = zly.Engine(weights_path, max_batch=n, max_dets=128, warmup_runs=1, flags=zly.FLAG_ASYNC_NMS | zly.FLAG_DUMP_LOGITS)
+    d = torch.from_numpy(frames).cuda()
+    e.detect_device(d.data_ptr(), n, 416, 416)
+    slabs = e.read_slabs(n)
+    checked = _check_taps(e, ref_bf16, (0, n // 2 + 1, n - 1), skip_ok=(".m.0.cv1", ".m.1.cv1"))
+    assert len(checked) >= 59, checked
+    compared = skipped = 0
+    for i in range(n):
+        gh = e.head_tensor(i)
+        _assert_bf16_close(gh[None], want16[i][None])
+        _assert_bf16_close(gh[None], want32[i][None])
+        c, sk, errors = compare_detection_sets(oracle, want32[i], slabs[i][1], 416, 416, band=BF16_FLIP_BAND)
+        assert not errors, (i, errors)
+        compared += c; skipped += sk
+    assert compared >= 5 * n, (compared, skipped)
+    e.close()
+
+
+@pytest.mark.parametrize("w,h,n,env", [(352, 288, 5, {}), (352, 288, 5, {"ZLY_NO_WRES": "1"}), (416, 416, 3, {"ZLY_STREAM_WGS": "8"}),
+                                       (224, 416, 4, {"ZLY_LDS_WGS_PER_CU": "1"})])
+def test_throughput_kernels_on_ragged_maps(weights_path, oracle, monkeypatch, w, h, n, env):
+    """conv3x3_lds_kernel, conv1x1_stream_kernel and bottleneck_pair_kernel forced onto small batches of ragged maps (88x72 ..
+    11x9, 104x104 .. 13x13, 56x104 .. 7x13: partial tiles on every edge, 13-row maps, last pixel groups that are not full,
+    persistent workgroups that loop over many items), every conv output against the bf16-rounding oracle."""
+    import yolov8_ref
+    for k, v in dict(ZLY_LDS_MIN_TILES="1", ZLY_STREAM_MIN_GROUPS="1", ZLY_PAIR_MIN_TILES="1", **env).items():
+        monkeypatch.setenv(k, v)
+    frames = zm.synth_frames(n, w, h, seed=31, rects=False)
+    x = _pre(oracle, frames, w, h)
+    ref = yolov8_ref.load(weights_path, "bf16")
+    want = ref.forward(torch.from_numpy(x)).numpy()
+    e = zly.Engine(weights_path, model_w=w, model_h=h, max_batch=n, warmup_runs=0, flags=zly.FLAG_DUMP_LOGITS)
+    got = e.forward(x)
+    checked = _check_taps(e, ref, range(n), skip_ok=(".m.0.cv1", ".m.1.cv1"))
+    assert len(checked) >= 59, checked
+    _assert_bf16_close(got, want)
+    e.close()
 
 
 def test_forward_bf16_vs_fp32_oracle(eng16, oracle, ref_fp32):
@@ -245,26 +354,26 @@ def test_detect_fp32_matches_full_cpu_pipeline(eng32, oracle, ref_fp32):
             assert abs(n - len(want)) <= 2 and _match(dets, want, oracle.iou, 0.5) or _match(want, dets, oracle.iou, 0.5)
 
 
-def test_detect_bf16_candidates_agree_with_fp32_oracle(eng16, oracle, ref_fp32):
-    """bf16 engine vs fp32 oracle at the anchor level: every anchor the oracle scores confidently above
-    the threshold (>= 0.5 + band) is a GPU candidate of the same class, and no GPU candidate is
-    confidently below it (< 0.5 - band) in the oracle."""
-    frames = zm.synth_frames(3, 416, 416, seed=5, rects=False)
+def test_detect_bf16_sets_match_fp32_oracle(eng16, oracle, ref_fp32):
+    """SURVEY 8c, set level, batch 1 (the latency path): the bf16 engine's FINAL detections against the fp32 oracle's
+    (oracle preprocess -> fp32 forward -> oracle decode/NMS), same class + IoU >= 0.9 + confidence within 2e-2, every
+    connected group of overlapping candidates compared exactly unless it contains a score within 2e-2 of the
+    confidence threshold or an IoU within 2e-2 of the NMS threshold (tests/parity_sets.py).  Includes a stretched
+    800x600 request (boxes normalised by the request size)."""
+    frames = list(zm.synth_frames(10, 416, 416, seed=5, rects=False)) + [zm.synth_frames(1, 800, 600, seed=3, rects=False)[0],
+                                                                            zm.synth_frames(1, 320, 240, seed=23)[0]]
     x = _pre(oracle, frames)
     heads = ref_fp32.forward(torch.from_numpy(x)).numpy()
-    total = 0
+    compared = skipped = 0
     for f, head in zip(frames, heads):
         dets, n = eng16.detect(f, cap=512)
+        assert n == len(dets)
         gh = eng16.head_tensor(0)
-        rs, gs = head[4:].max(0), gh[4:].max(0)
-        sure = rs >= 0.5 + BF16_FLIP_BAND
-        assert np.all(gs[sure] >= 0.5)
-        top2 = np.sort(head[4:], axis=0)[-2:]
-        clear = sure & (top2[1] - top2[0] > 2 * BF16_SCORE_MAX)         # both classes may move by the score tolerance
-        assert np.array_equal(head[4:].argmax(0)[clear], gh[4:].argmax(0)[clear])
-        assert np.all(rs[gs >= 0.5] >= 0.5 - BF16_FLIP_BAND)
-        total += n
-    assert total > 0
+        assert np.abs(gh[:4] - head[:4]).max() <= BF16_BOX_MAX and np.abs(gh[4:] - head[4:]).max() <= BF16_SCORE_MAX
+        c, sk, errors = compare_detection_sets(oracle, head, dets, f.shape[1], f.shape[0], band=BF16_FLIP_BAND)
+        assert not errors, errors
+        compared += c; skipped += sk
+    assert compared >= 80, (compared, skipped)
 
 
 def _mixed_frames():
@@ -372,6 +481,22 @@ def test_model_file_errors(weights_path, tmp_path):
     with pytest.raises(zly.ZlyError) as ei:
         zly.Engine(str(bad))
     assert ei.value.code == zly.ERR_MODEL_LOAD
+    # crafted records must not wrap the loader's bounds arithmetic (the file is re-read by the hot-reload watcher)
+    import struct
+    good = bytearray(open(weights_path, "rb").read())
+    rec0 = zm.HDR_SIZE
+    cases = {"huge_dims": (rec0 + 48, struct.pack("<II", 0x7fffffff, 0x7fffffff)),          # cin, cout: product wraps size_t
+             "w_off_wraps": (rec0 + 48 + 24, struct.pack("<Q", 2 ** 64 - 8)),                # w_off + nw * 4 wraps to a small number
+             "b_off_wraps": (rec0 + 48 + 32, struct.pack("<Q", 2 ** 64 - 4)),
+             "nc_out_of_range": (8, struct.pack("<I", 100000))}
+    for name, (off, patch) in cases.items():
+        blob = bytearray(good)
+        blob[off:off + len(patch)] = patch
+        f = tmp_path / (name + ".zlyw")
+        f.write_bytes(bytes(blob))
+        with pytest.raises(zly.ZlyError) as ei:
+            zly.Engine(str(f))
+        assert ei.value.code == zly.ERR_MODEL_LOAD, name
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -392,8 +517,11 @@ def test_640x640_fp32_and_bf16(weights_path, oracle, ref_fp32):
         own = oracle.postprocess(e.head_tensor(0), 640, 640)
         assert n == len(own) and det_fields_equal(dets, own[:512])
     got = e.forward(x)
-    db, ds = got[:, :4] - want[:, :4], got[:, 4:] - want[:, 4:]
-    assert _rms(db) <= 1.6 * BF16_BOX_RMS and _rms(ds) <= BF16_SCORE_RMS            # boxes scale with the input size
+    _assert_bf16_close(got, want)                                                  # same strides, same pixel tolerance
+    for f, head in zip(frames, want):
+        dets, n = e.detect(f, cap=512)
+        c, sk, errors = compare_detection_sets(oracle, head, dets, 640, 640, band=BF16_FLIP_BAND)
+        assert not errors and c > 0, errors
     e.close()
 
 
@@ -631,11 +759,11 @@ def test_four_class_cs16_head(tmp_path, oracle):
     assert np.abs(got[:, :4] - want[:, :4]).max() <= 4 * FP32_BOX_TOL * scale
     assert np.abs(got[:, 4:] - want[:, 4:]).max() <= 2 * FP32_SCORE_TOL
     e.close()
-    e = zly.Engine(p, dtype=zly.DTYPE_BF16, max_batch=3, max_dets=512, conf_thr=0.5, warmup_runs=0)
+    e = zly.Engine(p, dtype=zly.DTYPE_BF16, max_batch=3, max_dets=512, conf_thr=0.3, warmup_runs=0)
     total = 0
     for f in frames:
         dets, n = e.detect(f, cap=512)
-        own = oracle.postprocess(e.head_tensor(0), 416, 416, 0.5, 0.45)
+        own = oracle.postprocess(e.head_tensor(0), 416, 416, 0.3, 0.45)
         assert n == len(own) and det_fields_equal(dets, own[:512])
         assert n == 0 or (dets["class_id"][:min(n, 512)] < 4).all()
         total += n

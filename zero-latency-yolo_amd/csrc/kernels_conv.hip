@@ -322,8 +322,10 @@ __global__ __launch_bounds__(256) void conv1x1_stream_kernel(const ConvArgs a, i
     if (g >= ngroups) return;
 
     // Buffer resources over the input view and the output view: addresses are (wave-uniform byte offset of the pixel
-    // group: SGPR) + (per-lane byte offset, computed once: VGPR) + immediate, out-of-range pixels of the last group read
-    // zeros and their stores are dropped by the hardware range check -- no per-group address or bounds VALU at all.
+    // group) + (per-lane byte offset, computed once) + immediate, both in the VGPR operand -- soffset is NOT part of the
+    // hardware range check, so a group offset passed there would let the last, partial group read past the tensor --
+    // out-of-range pixels of the last group read zeros and their stores are dropped by the range check: one v_add per
+    // access, no bounds VALU.
     const bf16_t* inb = static_cast<const bf16_t*>(a.in) + a.in_co;
     bf16_t* outb = static_cast<bf16_t*>(a.out) + a.out_co + blockIdx.y * (CT * 16);
     const unsigned in_bytes = (unsigned)(((size_t)(a.M - 1) * a.in_cs + min(a.Cin, a.in_cs - a.in_co)) * 2);
@@ -352,12 +354,19 @@ __global__ __launch_bounds__(256) void conv1x1_stream_kernel(const ConvArgs a, i
     for (int c = 0; c < CT; ++c)
         biasr[c] = *reinterpret_cast<const f32x4*>(a.bias + blockIdx.y * (CT * 16) + (c >> 1) * 32 + kq * 8 + (c & 1) * 4);
 
+    // K padding (Cin % 32 != 0, e.g. the 48-channel concat of model.2.cv2): the lanes of the last k-step whose channels lie
+    // beyond Cin would read the next pixel's first channels; their weights are zero, but 0 * Inf/NaN is not, so they are
+    // masked like conv_igemm_kernel does (a per-lane constant: four v_cndmask per fragment of the last k-step)
+    const bool kpad_lane = (NK - 1) * 32 + kq * 8 >= a.Cin;
     auto load_group = [&](int grp, u32x4 (&x)[PT][NK]) {
         const int so = grp * gin;
 #pragma unroll
         for (int t = 0; t < PT; ++t)
 #pragma unroll
-            for (int s = 0; s < NK; ++s) x[t][s] = __builtin_amdgcn_raw_buffer_load_b128(rin, vin[t] + s * 64, so, 0);
+            for (int s = 0; s < NK; ++s) {
+                x[t][s] = __builtin_amdgcn_raw_buffer_load_b128(rin, vin[t] + so + s * 64, 0, 0);
+                if (s == NK - 1 && kpad_lane) x[t][s] = u32x4{0u, 0u, 0u, 0u};
+            }
     };
     auto compute = [&](int grp, const u32x4 (&x)[PT][NK]) {
         f32x4 acc[CT][PT];
@@ -869,7 +878,8 @@ static bool pick_lds_config(int stride, int cin, int cout_pad, int n, int Ho, in
     if (stride == 1 && Ho <= 14) pt = 1;                                            // 13-row maps: 4 x 4 rows
     if (ct == 5 && (pt > 1 || stride == 2)) { if (stride == 2) return false; pt = 1; }  // those variants do not fit 256 registers (2 waves per SIMD) without spilling
     const long tiles = (long)n * tx * ((Ho + 4 * pt - 1) / (4 * pt));
-    if (tiles * ytiles < 384) return false;                                         // too small: direct kernel
+    const char* lm = getenv("ZLY_LDS_MIN_TILES");                                   // tuning / tests: force the LDS kernel onto small launches
+    if (tiles * ytiles < (lm ? atol(lm) : 384)) return false;                       // too small: direct kernel
     cfg->lds = 1; cfg->ct = ct; cfg->pt = pt; cfg->ksplit = 1; cfg->fastk = 1;
     return true;
 }

@@ -51,6 +51,7 @@ int load_zlyw(const char* path, ModelFile* out, std::string* err)
     if (memcmp(h.magic, "ZLYW", 4) != 0 || h.version != 1) { *err = "bad magic/version (expected ZLYW v1)"; return ZLY_ERR_MODEL_LOAD; }
     if (h.num_convs == 0 || h.num_convs > 4096 ||
         sizeof(FileHeader) + (size_t)h.num_convs * sizeof(FileRec) > data.size()) { *err = "corrupt conv table"; return ZLY_ERR_MODEL_LOAD; }
+    if (h.nc < 1 || h.nc > 1024 || h.reg_max < 1 || h.reg_max > 64) { *err = "corrupt header (nc / reg_max out of range)"; return ZLY_ERR_MODEL_LOAD; }
     out->nc = (int)h.nc;
     out->reg_max = (int)h.reg_max;
     for (int i = 0; i < 5; ++i) out->ch[i] = (int)h.ch[i];
@@ -66,9 +67,12 @@ int load_zlyw(const char* path, ModelFile* out, std::string* err)
         nm[48] = 0;
         c.name = nm;
         c.cin = (int)r.cin; c.cout = (int)r.cout; c.k = (int)r.k; c.stride = (int)r.stride; c.act = (int)r.act;
-        const size_t nw = (size_t)c.cout * c.cin * c.k * c.k;
-        if (c.cin <= 0 || c.cout <= 0 || (c.k != 1 && c.k != 3) || (c.stride != 1 && c.stride != 2) ||
-            r.w_off + nw * 4 > data.size() || r.b_off + (size_t)c.cout * 4 > data.size()) {
+        // widths are bounded before any product is formed (a crafted record must not wrap size_t), and the payload ranges
+        // are checked without additions that can wrap: this file is re-read by the hot-reload watcher
+        const bool dims_ok = c.cin > 0 && c.cout > 0 && c.cin <= 65536 && c.cout <= 65536 && (c.k == 1 || c.k == 3) && (c.stride == 1 || c.stride == 2);
+        const size_t nw = dims_ok ? (size_t)c.cout * c.cin * c.k * c.k : 0;
+        const size_t fsz = data.size();
+        if (!dims_ok || r.w_off > fsz || nw * 4 > fsz - r.w_off || r.b_off > fsz || (size_t)c.cout * 4 > fsz - r.b_off) {
             *err = "corrupt conv record: " + c.name;
             return ZLY_ERR_MODEL_LOAD;
         }

@@ -208,77 +208,96 @@ def read_zlyw(path: str):
 # Real YOLOv8 weights carry folded BatchNorm statistics that keep every layer's activations O(1);
 # plain He-style random weights do not (SiLU has no stable variance fixed point: activations grew
 # to std ~140 by the head).  SYNTH_GAIN is the per-conv factor g in std = g / sqrt(fan_in) that
-# makes the pre-activation std 1.0 (box logits 1.5) on the seeded 416x416 calibration frames.  The
+# makes the pre-activation std SYNTH_ACT_STD on the seeded 416x416 calibration frames.  The
 # table was produced ONCE, offline, by oracle/calibrate_synth.py (LSUV-style, one forward pass) and
 # is data here, so that the generator needs no forward pass and imports nothing from oracle/.
+#
+# Two properties of a TRAINED detector are built in, because the bf16 tolerance of SURVEY.md 8c
+# (box <= 1.5 px, score <= 2e-2) is only meaningful on a network that has them:
+#  * noise stability.  A random deep net calibrated to pre-activation std 1.0 is in the chaotic regime:
+#    a perturbation grows ~1.2x per layer, so the 2^-9 rounding noise of bf16 activations reached 7 % of
+#    the signal at the Detect head (measured on the CPU: bf16-rounding oracle vs fp32 oracle, round 1).
+#    At std 0.25 SiLU works on its near-linear part, perturbations neither grow nor shrink, and the
+#    head sees ~1 % = 2^-9 * sqrt(depth), which is what bf16 inference of a trained model shows.
+#  * peaked DFL distributions.  The final box conv (cv2.L.2) emits, per box side, 16 logits
+#    z_i = -a*i^2 + 2a*i*mu  (+ a term constant in i), i.e. softmax_i = a discretised Gaussian of
+#    mean mu and sigma = 1/sqrt(2a) bins, where mu = w_mu . x + b_mu is LINEAR in the features: row i
+#    of the conv is 2a*i*w_mu, bias -a*i^2 + 2a*i*b_mu.  With a = 0.5 (sigma = 1 bin) the DFL
+#    expectation is mu itself, as in a trained head that puts its mass on the two bins around the
+#    regressed distance -- not the near-uniform softmax of random logits whose expectation amplifies
+#    logit noise by several bins.
 SYNTH_SEED = 8
 BIAS_STD = 0.05
-DFL_BIAS = 1.0            # box-branch final bias (ultralytics Detect.bias_init analogue)
-CLS_LOGIT_SHIFT = -4.8    # class-branch final bias; puts ~1 % of anchors above conf 0.5 on noise frames
+SYNTH_ACT_STD = 0.25      # pre-activation std of every SiLU conv (calibration target)
+DFL_ALPHA = 0.5           # Gaussian DFL: sigma = 1 bin
+DFL_MU_BIAS = 4.0         # mean regressed distance in bins (boxes ~8 bins = 64 / 128 / 256 px wide)
+DFL_MU_STD = 0.3          # std of the regressed distance over anchors (calibration target, bins)
+CLS_LOGIT_STD = 0.7       # std of the class logits (calibration target)
+CLS_LOGIT_SHIFT = -2.75   # class-branch final bias; puts ~1 % of anchors above conf 0.5 on noise frames
 SYNTH_GAIN: Dict[str, float] = {
-    "model.0": 3.6643,
-    "model.1": 1.8027,
-    "model.2.cv1": 1.8269,
-    "model.2.m.0.cv1": 1.8764,
-    "model.2.m.0.cv2": 1.7797,
-    "model.2.cv2": 1.5978,
-    "model.3": 1.7415,
-    "model.4.cv1": 1.8730,
-    "model.4.m.0.cv1": 1.8319,
-    "model.4.m.0.cv2": 1.7611,
-    "model.4.m.1.cv1": 1.2753,
-    "model.4.m.1.cv2": 1.7753,
-    "model.4.cv2": 1.3218,
-    "model.5": 1.7712,
-    "model.6.cv1": 1.7718,
-    "model.6.m.0.cv1": 1.7174,
-    "model.6.m.0.cv2": 1.8384,
-    "model.6.m.1.cv1": 1.2422,
-    "model.6.m.1.cv2": 1.8498,
-    "model.6.cv2": 1.2983,
-    "model.7": 1.8381,
-    "model.8.cv1": 1.7790,
-    "model.8.m.0.cv1": 1.7903,
-    "model.8.m.0.cv2": 1.8016,
-    "model.8.cv2": 1.5082,
-    "model.9.cv1": 1.7939,
-    "model.9.cv2": 0.8837,
-    "model.12.cv1": 1.8244,
-    "model.12.m.0.cv1": 1.6148,
-    "model.12.m.0.cv2": 1.9027,
-    "model.12.cv2": 1.7182,
-    "model.15.cv1": 1.8125,
-    "model.15.m.0.cv1": 1.9693,
-    "model.15.m.0.cv2": 1.8546,
-    "model.15.cv2": 1.7808,
-    "model.16": 1.8890,
-    "model.18.cv1": 1.8442,
-    "model.18.m.0.cv1": 1.8129,
-    "model.18.m.0.cv2": 1.8503,
-    "model.18.cv2": 1.8183,
-    "model.19": 1.7555,
-    "model.21.cv1": 1.8484,
-    "model.21.m.0.cv1": 1.7577,
-    "model.21.m.0.cv2": 1.7880,
-    "model.21.cv2": 1.8006,
-    "model.22.cv2.0.0": 1.8828,
-    "model.22.cv2.0.1": 1.7913,
-    "model.22.cv2.0.2": 2.6417,
-    "model.22.cv2.1.0": 1.7405,
-    "model.22.cv2.1.1": 1.8234,
-    "model.22.cv2.1.2": 2.6174,
-    "model.22.cv2.2.0": 1.8975,
-    "model.22.cv2.2.1": 1.8689,
-    "model.22.cv2.2.2": 2.7418,
-    "model.22.cv3.0.0": 1.8901,
-    "model.22.cv3.0.1": 1.8143,
-    "model.22.cv3.0.2": 1.8162,
-    "model.22.cv3.1.0": 1.7667,
-    "model.22.cv3.1.1": 1.8474,
-    "model.22.cv3.1.2": 1.7116,
-    "model.22.cv3.2.0": 1.7800,
-    "model.22.cv3.2.1": 1.8568,
-    "model.22.cv3.2.2": 1.9786,
+    "model.0": 0.9161,
+    "model.1": 1.9635,
+    "model.2.cv1": 2.0015,
+    "model.2.m.0.cv1": 2.0066,
+    "model.2.m.0.cv2": 1.8224,
+    "model.2.cv2": 1.7142,
+    "model.3": 1.8793,
+    "model.4.cv1": 2.1230,
+    "model.4.m.0.cv1": 1.9933,
+    "model.4.m.0.cv2": 2.0012,
+    "model.4.m.1.cv1": 1.3976,
+    "model.4.m.1.cv2": 1.8836,
+    "model.4.cv2": 1.4595,
+    "model.5": 1.9976,
+    "model.6.cv1": 1.8835,
+    "model.6.m.0.cv1": 1.8026,
+    "model.6.m.0.cv2": 2.2138,
+    "model.6.m.1.cv1": 1.3479,
+    "model.6.m.1.cv2": 2.0085,
+    "model.6.cv2": 1.3720,
+    "model.7": 1.9759,
+    "model.8.cv1": 1.9129,
+    "model.8.m.0.cv1": 1.8854,
+    "model.8.m.0.cv2": 2.0056,
+    "model.8.cv2": 1.6757,
+    "model.9.cv1": 1.8604,
+    "model.9.cv2": 1.3642,
+    "model.12.cv1": 2.0366,
+    "model.12.m.0.cv1": 1.8865,
+    "model.12.m.0.cv2": 2.0101,
+    "model.12.cv2": 1.9545,
+    "model.15.cv1": 2.0030,
+    "model.15.m.0.cv1": 2.2408,
+    "model.15.m.0.cv2": 1.9484,
+    "model.15.cv2": 1.8297,
+    "model.16": 1.9649,
+    "model.18.cv1": 1.9535,
+    "model.18.m.0.cv1": 1.9982,
+    "model.18.m.0.cv2": 2.1151,
+    "model.18.cv2": 1.9064,
+    "model.19": 1.8504,
+    "model.21.cv1": 2.0813,
+    "model.21.m.0.cv1": 2.1656,
+    "model.21.m.0.cv2": 1.9412,
+    "model.21.cv2": 1.9640,
+    "model.22.cv2.0.0": 1.9791,
+    "model.22.cv2.0.1": 1.9290,
+    "model.22.cv2.0.2": 2.4489,
+    "model.22.cv2.1.0": 1.8420,
+    "model.22.cv2.1.1": 1.9390,
+    "model.22.cv2.1.2": 2.9245,
+    "model.22.cv2.2.0": 1.9841,
+    "model.22.cv2.2.1": 1.9732,
+    "model.22.cv2.2.2": 2.4386,
+    "model.22.cv3.0.0": 1.9352,
+    "model.22.cv3.0.1": 1.9841,
+    "model.22.cv3.0.2": 6.0178,
+    "model.22.cv3.1.0": 1.7576,
+    "model.22.cv3.1.1": 2.1012,
+    "model.22.cv3.1.2": 5.3266,
+    "model.22.cv3.2.0": 2.0347,
+    "model.22.cv3.2.1": 2.0770,
+    "model.22.cv3.2.2": 5.9230,
 }
 
 
@@ -296,7 +315,14 @@ def synth_weights(spec: ModelSpec, seed: int = SYNTH_SEED, gains: Dict[str, floa
         w *= np.float32(gain / np.sqrt(fan_in))
         b = rng.standard_normal((c.cout,), dtype=np.float32) * np.float32(BIAS_STD)
         if c.name.startswith("model.22.cv2.") and c.name.endswith(".2"):
-            b = b + np.float32(DFL_BIAS)
+            # Gaussian DFL head (see above): side s uses filter row 16*s as w_mu and its bias (+ DFL_MU_BIAS) as b_mu
+            assert c.cout == 4 * spec.reg_max and c.k == 1
+            bins = np.arange(spec.reg_max, dtype=np.float32)
+            w_mu = w[::spec.reg_max].copy()                                  # [4][cin][1][1]
+            b_mu = b[::spec.reg_max].copy() + np.float32(DFL_MU_BIAS)        # [4]
+            two_a = np.float32(2.0 * DFL_ALPHA)
+            w = (two_a * bins[None, :, None, None, None] * w_mu[:, None]).reshape(c.cout, c.cin, 1, 1)
+            b = (-np.float32(DFL_ALPHA) * bins[None, :] ** 2 + two_a * bins[None, :] * b_mu[:, None]).reshape(c.cout)
         if c.name.startswith("model.22.cv3.") and c.name.endswith(".2"):
             b = b + np.float32(CLS_LOGIT_SHIFT)
         out[c.name] = (w.astype(np.float32), b.astype(np.float32))
