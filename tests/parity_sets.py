@@ -7,9 +7,10 @@ and the box that survives may suppress a third one (a cascade).  Cascades cannot
 graph  {nodes: oracle anchors scoring >= conf - band; edges: same class and IoU >= iou_thr - band}, because greedy
 class-aware NMS (reference onnx_engine.cpp:837-878) only ever lets a box act on a same-class box it overlaps by more
 than the threshold, in either of the two runs being compared.  So:
-  * a component is AMBIGUOUS when it holds a node with |score - conf| <= band, an edge with |IoU - iou_thr| <= band, or
-    two overlapping nodes whose scores are within band of each other (their greedy order may swap) and which do not
-    suppress the same third nodes: both outcomes are legitimate there and it is skipped (and counted);
+  * a component is AMBIGUOUS when it holds a node with |score - conf| <= band, an anchor whose two best classes score within
+    band of each other (the arg-max may pick either: the anchor is then a node of both classes), an edge with
+    |IoU - iou_thr| <= band, or two overlapping nodes whose scores are within band of each other (their greedy order may
+    swap) and which do not suppress the same third nodes: both outcomes are legitimate there and it is skipped (and counted);
   * in every other component the two detection sets must be identical: same number, one-to-one matched with the same
     class, IoU >= min_iou and |confidence difference| <= band;
   * every detection of the engine must land on an oracle node (same class, IoU >= min_iou): a detection from nowhere
@@ -39,9 +40,19 @@ def compare_detection_sets(oracle, ref_head, got, img_w, img_h, conf=0.5, iou_th
     """oracle: tests/oracle_lib.Oracle; ref_head: fp32 oracle head tensor [4+nc][N] of the frame; got: the engine's
     detections (structured zly_det array).  Returns (n_compared, n_skipped, errors): detections compared exactly,
     oracle detections skipped inside ambiguous components, list of error strings (empty = parity holds)."""
-    nodes = oracle.decode(ref_head, img_w, img_h, max(conf - band, 1e-6))
     want = oracle.postprocess(ref_head, img_w, img_h, conf, iou_thr)
     errors = []
+    # nodes: (anchor, class) pairs the engine may legitimately report -- the anchor's best class, plus every class within
+    # `band` of it, when they score >= conf - band (postProcess keeps the arg-max class only, onnx_engine.cpp:787-799)
+    ref_head = np.asarray(ref_head, dtype=np.float32)
+    sc = ref_head[4:]
+    top = sc.max(0)
+    cls_i, anc_i = np.nonzero((sc >= np.maximum(top - band, conf - band)[None]) & (top >= conf - band)[None])
+    per_anchor = np.bincount(anc_i, minlength=sc.shape[1])
+    nodes = np.zeros(len(anc_i), dtype=[("x", "<f8"), ("y", "<f8"), ("w", "<f8"), ("h", "<f8"), ("confidence", "<f8"), ("class_id", "<i4")])
+    nodes["x"] = ref_head[0, anc_i].astype(np.float64) / img_w; nodes["y"] = ref_head[1, anc_i].astype(np.float64) / img_h
+    nodes["w"] = ref_head[2, anc_i].astype(np.float64) / img_w; nodes["h"] = ref_head[3, anc_i].astype(np.float64) / img_h
+    nodes["confidence"] = sc[cls_i, anc_i]; nodes["class_id"] = cls_i
     nb = _boxes(nodes)
     n = len(nodes)
     comp = np.arange(n)
@@ -52,7 +63,7 @@ def compare_detection_sets(oracle, ref_head, got, img_w, img_h, conf=0.5, iou_th
             i = comp[i]
         return i
 
-    amb_node = np.abs(nodes["confidence"].astype(np.float64) - conf) <= band if n else np.zeros(0, bool)
+    amb_node = (np.abs(nodes["confidence"] - conf) <= band) | (per_anchor[anc_i] > 1) if n else np.zeros(0, bool)
     amb_edges = []
     if n:
         iou = _iou_matrix(nb, nb)
