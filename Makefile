@@ -34,13 +34,16 @@ $(OUT)/libzly.so: $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
 
 # ---- host side: the reference's IInferenceEngine plugin interface over the C ABI -----------------
-host: $(OUT)/libzly_plugin.so $(OUT)/test_hip_engine $(OUT)/test_wire $(OUT)/test_game_step $(OUT)/test_frame_server
+host: $(OUT)/libzly_plugin.so $(OUT)/test_hip_engine $(OUT)/test_wire $(OUT)/test_game_step $(OUT)/test_frame_server $(OUT)/zly_h2h_bench
 
 $(OUT)/libzly_plugin.so: $(HOST)/hip_inference_engine.cpp $(HOST)/hip_inference_engine.h $(HOST)/zly_sha256.hpp $(HOST)/zly_compat.hpp include/zly.h $(OUT)/libzly.so
 	$(CXX) -O2 -std=c++17 -fPIC -shared -Iinclude -I$(HOST) -o $@ $(HOST)/hip_inference_engine.cpp -L$(OUT) -lzly -pthread -Wl,-rpath,'$$ORIGIN'
 
 $(OUT)/test_hip_engine: tests/cpp/test_hip_engine.cpp $(OUT)/libzly_plugin.so
 	$(CXX) -O2 -std=c++17 -Iinclude -I$(HOST) -o $@ tests/cpp/test_hip_engine.cpp -Wl,--no-as-needed -L$(OUT) -lzly_plugin -lzly -pthread -Wl,-rpath,'$$ORIGIN'
+
+$(OUT)/zly_h2h_bench: tests/cpp/bench_h2h.cpp $(OUT)/libzly_plugin.so
+	$(CXX) -O2 -std=c++17 -Wall -Iinclude -I$(HOST) -o $@ tests/cpp/bench_h2h.cpp -Wl,--no-as-needed -L$(OUT) -lzly_plugin -lzly -pthread -Wl,-rpath,'$$ORIGIN'
 
 $(OUT)/test_frame_server: tests/cpp/test_frame_server.cpp $(HOST)/zly_frame_server.hpp $(HOST)/zly_wire.hpp $(HOST)/zly_game_step.hpp $(OUT)/libzly_plugin.so
 	$(CXX) -O2 -std=c++17 -Wall -Iinclude -I$(HOST) -o $@ tests/cpp/test_frame_server.cpp -Wl,--no-as-needed -L$(OUT) -lzly_plugin -lzly -pthread -Wl,-rpath,'$$ORIGIN'

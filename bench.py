@@ -145,6 +145,28 @@ def cpu_baseline(frames_np, seconds=12.0):
             "note": "ORT-CPU unavailable offline; torch-CPU stand-in for the forward pass. 60 FPS is the reference's unmeasured sleep-throttle target (README.md:16, onnx_engine.cpp:462-466)"}
 
 
+def host_to_host(threads, seconds=4.0, max_batch=64):
+    """SURVEY 8d's throughput metric proper: request bytes in HOST memory -> detections in HOST memory, `threads` submitting host
+    threads (config 3: >= 8).  Measured natively by _build/zly_h2h_bench (tests/cpp/bench_h2h.cpp: no interpreter between the
+    threads and the C ABI), once through zly_submit / zly_wait and once through HipInferenceEngine::submitInference ->
+    InferenceCallback (what the reference's NetworkServer drives).  Frames are pageable host memory; the figure includes the
+    one host copy into the pinned ring, the PCIe upload (overlapped with the previous batch's compute) and the slab download."""
+    import subprocess
+    exe = os.path.join(ROOT, "zero-latency-yolo_amd", "_build", "zly_h2h_bench")
+    out = {"threads": threads, "pcie_ceiling_frames_per_sec": round(63e9 / 519168, 0),
+           "note": "pageable host frames -> zly_submit (copy into the pinned ring on the submitting thread) -> H2D on a copy stream beside "
+                   "the previous batch's compute -> path -> slab D2H -> zly_wait; 63 GB/s PCIe Gen5 x16 / 519168 B = 121 k frames/s ceiling"}
+    for mode in ("cabi", "plugin"):
+        try:
+            r = subprocess.run([exe, zly.DEFAULT_WEIGHTS, mode, str(threads), str(seconds), str(max_batch)],
+                               capture_output=True, text=True, timeout=120)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            out[mode] = json.loads(line[-1]) if (r.returncode == 0 and line) else {"error": (r.stderr or r.stdout)[-400:], "rc": r.returncode}
+        except Exception as exc:       # noqa: BLE001  (a failing leg must not take the headline down)
+            out[mode] = {"error": repr(exc)}
+    return out
+
+
 def main():
     # The driver reads ONE JSON line from stdout.  Libraries underneath print there too (RCCL writes its
     # version banner to stdout when the communicator is created), so everything but the final line is sent
@@ -314,6 +336,12 @@ def run():
             result["candidates_per_frame_last_profiled_batch"] = {"median": float(np.median([int(h["n_candidates"]) for h in hdrs])),
                                                                   "max": int(max(int(h["n_candidates"]) for h in hdrs)),
                                                                   "kept_max": int(max(int(h["n_kept"]) for h in hdrs))}
+    if rank == 0 and world == 1 and not a.no_extras and os.environ.get("ZLY_BENCH_NO_H2H") != "1":
+        log("host-to-host throughput leg (native driver, 2 x ~5 s)")
+        h2h = host_to_host(max(8, min(12, host_cores() - 3)))
+        result["throughput_host_to_host"] = h2h
+        if "frames_per_sec" in h2h.get("cabi", {}):
+            result["throughput_host_to_host"]["frac_of_device_resident"] = round(h2h["cabi"]["frames_per_sec"] / value, 3)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(frames_np[:8])
         result["speedup_vs_cpu_baseline"] = round(value / result["cpu_baseline"]["value"], 1)

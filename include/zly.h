@@ -15,6 +15,9 @@
  *                              postProcess/applyNMS), one frame   onnx_engine.cpp:518-646
  *   zly_detect_batch           the "dynamic batching" loop that the reference leaves as a TODO and
  *                              runs frame by frame                 onnx_engine.cpp:320-365
+ *   zly_submit / zly_poll / zly_wait   OnnxInferenceEngine::submitInference + the result hand-over of its
+ *                              inference thread: the asynchronous, pipelined host-to-host path
+ *                                                                  onnx_engine.cpp:223-261, 315-398
  *   zly_detect_device          same path with frames already resident in HBM (no reference
  *                              counterpart; used by bench.py and the multi-GPU sharding)
  *   zly_preprocess             OnnxInferenceEngine::preProcess     onnx_engine.cpp:649-700
@@ -51,6 +54,7 @@ extern "C" {
 #define ZLY_ERR_MODEL_LOAD      202
 #define ZLY_ERR_INVALID_INPUT   203
 #define ZLY_ERR_SYSTEM          300
+#define ZLY_PENDING             1   /* zly_poll only: the ticket's batch has not completed yet (not an error) */
 
 #define ZLY_DTYPE_FP32 0   /* fp32 activations + exact-fp32 MFMA: verification mode */
 #define ZLY_DTYPE_BF16 1   /* bf16 activations/weights, fp32 accumulate: production mode */
@@ -107,8 +111,15 @@ typedef struct zly_config {
 typedef struct zly_stats {
     uint64_t inference_count;
     uint64_t inference_errors;
-    double total_preprocess_ms, total_forward_ms, total_postprocess_ms;   /* device time, profiled calls only */
+    double total_preprocess_ms, total_forward_ms, total_postprocess_ms;   /* device time, zly_profile_ops calls only */
     double last_detect_ms;                                                /* host wall time of the last zly_detect */
+    /* production sampling (the reference accumulates its three phase timers per frame, onnx_engine.cpp:530-557,605-618):
+     * every 16th call of a detect path is bracketed by hipEvents -- preprocess = the preprocess / fused preprocess+stem
+     * kernel, forward = everything up to and including the Detect tail (decode + threshold are fused into it),
+     * postprocess = NMS.  Sums over the sampled calls; per-frame average = sampled_*_ms / sampled_frames. */
+    uint64_t sampled_frames;
+    double sampled_preprocess_ms, sampled_forward_ms, sampled_postprocess_ms;
+    uint64_t batches;                                                     /* calls of a detect path (any entry point) */
 } zly_stats;
 
 typedef struct zly_op_info {
@@ -135,6 +146,26 @@ int32_t zly_detect(zly_engine* e, const uint8_t* bgr, size_t nbytes, int32_t w, 
 /* n frames (n <= max_batch), each with its own size.  out is [n][cap]; n_out is [n]. */
 int32_t zly_detect_batch(zly_engine* e, int32_t n, const uint8_t* const* bgr, const size_t* nbytes,
                          const int32_t* w, const int32_t* h, zly_det* out, int32_t cap, int32_t* n_out);
+
+/* --- asynchronous, pipelined host-to-host path ------------------------------------------------------
+ * The throughput path of a server: many host threads hand over frames, the engine batches them and overlaps the PCIe
+ * transfers with compute.  Engine-owned ring of pinned staging slots (ZLY_STAGE_SLOTS, default 4; each holds one batch of
+ * up to max_batch frames / ZLY_STAGE_MB megabytes, default 1.25 x max_batch model-sized frames):
+ *   zly_submit   (any thread, concurrently) reserves a frame slot in the batch being filled and copies the pixels into
+ *                pinned memory ON THE CALLING THREAD -- the one copy of the request the reference makes too
+ *                (onnx_engine.cpp:233-235) -- then returns a ticket; it blocks only while every ring slot is busy.
+ *   dispatch     an engine-owned thread closes the filling batch as soon as fewer than two batches are in flight (a lone
+ *                frame is served at once, a backlog at full batches: no batching window), uploads it on a copy stream
+ *                while the previous batch computes, runs the path, and downloads the slabs on a third stream.
+ *   zly_wait     blocks until the ticket's batch is back in host memory and copies that frame's detections
+ *                (min(n, cap) to out, un-capped count to *n_out; timestamps = completion time, onnx_engine.cpp:813-815);
+ *                zly_poll is the non-blocking check (ZLY_OK = ready, ZLY_PENDING = not yet).
+ * Every ticket must be consumed by exactly one zly_wait (its ring slot is recycled when all its tickets are); a failed
+ * batch returns its error code from zly_wait for each of its tickets.  Wrong byte counts fail in zly_submit with
+ * ZLY_ERR_INVALID_INPUT (onnx_engine.cpp:659-665) and produce no ticket. */
+int32_t zly_submit(zly_engine* e, const uint8_t* bgr, size_t nbytes, int32_t w, int32_t h, uint64_t* ticket);
+int32_t zly_poll(zly_engine* e, uint64_t ticket);
+int32_t zly_wait(zly_engine* e, uint64_t ticket, zly_det* out, int32_t cap, int32_t* n_out);
 
 /* n frames of identical size, contiguous in DEVICE memory ([n][h][w][3] u8).  Enqueues the whole
  * path on `stream` (a hipStream_t, NULL = the engine's own stream) and returns without

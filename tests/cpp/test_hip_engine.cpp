@@ -15,7 +15,9 @@
 #include "zly_compat.hpp"
 #include "hip_inference_engine.h"
 
+#include <atomic>
 #include <chrono>
+#include <cstdlib>
 #include <condition_variable>
 #include <cstdio>
 #include <cstring>
@@ -101,6 +103,24 @@ int main(int argc, char** argv)
         return probe_only ? 0 : 4;
     }
 
+    // ZLY_TEST_POLL_STATUS=1: a second thread calls getStatus() / getQueueSize() in a tight loop while the burst is served, as the
+    // reference's monitor thread does every 5 s (server/main.cpp:103-104): no call may wait for a running batch
+    std::atomic<bool> poll_stop{false};
+    std::atomic<long> poll_calls{0};
+    double poll_max_ms = 0;
+    std::thread poller;
+    if (std::getenv("ZLY_TEST_POLL_STATUS")) {
+        poller = std::thread([&] {
+            while (!poll_stop) {
+                const auto t0 = std::chrono::steady_clock::now();
+                auto st = engine->getStatus();
+                (void)engine->getQueueSize();
+                const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                if (ms > poll_max_ms) poll_max_ms = ms;
+                poll_calls++;
+            }
+        });
+    }
     size_t expected = 0;
     for (size_t i = 0; i < frames.size(); ++i) {
         InferenceRequest r;
@@ -123,6 +143,11 @@ int main(int argc, char** argv)
     }
     // give a wrongly delivered extra callback (for the invalid frame) a moment to show up
     std::this_thread::sleep_for(std::chrono::milliseconds(50));
+    if (poller.joinable()) {
+        poll_stop = true;
+        poller.join();
+        js << "\"status_poll\":{\"calls\":" << poll_calls.load() << ",\"max_ms\":" << poll_max_ms << "},";
+    }
 
     auto status = engine->getStatus();
     js << "\"queue_size_after\":" << engine->getQueueSize() << ",";

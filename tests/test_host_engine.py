@@ -158,3 +158,25 @@ def test_host_engine_hot_reload(tmp_path, weights_path):
     for a_, b_ in zip(j["results"], j["results_after_reload"]):
         differs = differs or a_["dets"] != b_["dets"]
     assert differs                                                                        # the two models do not detect the same
+
+
+@pytest.mark.gpu
+def test_host_engine_status_during_a_burst(tmp_path, weights_path):
+    """getStatus() from a second thread while a 48-frame burst is being served (the reference's monitor thread polls it,
+    server/main.cpp:103-104): every call returns promptly -- it reads cached counters and never waits for the batch on the
+    device -- and the per-phase device times, sampled by the engine in production (the reference accumulates its phase
+    timers per frame, onnx_engine.cpp:530-557,605-618), are non-zero afterwards."""
+    _ensure_bin()
+    frames = list(zm.synth_frames(48, 416, 416, seed=9, rects=False))
+    fpath, out = tmp_path / "frames.bin", tmp_path / "out.json"
+    _write_frames(fpath, frames)
+    env = dict(os.environ, ZLY_TEST_POLL_STATUS="1", ZLY_MAX_BATCH="8")
+    r = subprocess.run([BIN, weights_path, str(fpath), str(out)], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr
+    j = json.loads(out.read_text())
+    assert [x["frame_id"] for x in j["results"]] == list(range(48))
+    st = j["status"]
+    assert j["status_poll"]["calls"] > 20 and j["status_poll"]["max_ms"] < 50.0, j["status_poll"]
+    assert float(st["avg_preprocessing_time_ms"]) > 0 and float(st["avg_postprocessing_time_ms"]) > 0 and float(st["avg_forward_time_ms"]) > 0, st
+    assert float(st["avg_preprocessing_time_ms"]) < 5 and float(st["avg_forward_time_ms"]) < 20
+    assert 6 <= int(st["batches"]) <= 48

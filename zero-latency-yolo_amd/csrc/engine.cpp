@@ -12,10 +12,14 @@
 #include "weights.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 #include <string.h>
 #include <stdio.h>
@@ -71,6 +75,8 @@ struct Op {
     double flops = 0, bytes = 0;
 };
 
+struct Ingest;        // pipelined host-to-host path (zly_submit / zly_wait), below
+
 }  // namespace zly
 
 using namespace zly;
@@ -108,7 +114,14 @@ struct zly_engine {
     int last_async = -1;              // parity of the last deferred NMS, -1 = none outstanding
     unsigned char* d_slabs = nullptr; // [max_batch][slab_bytes]
     FrameDesc* d_desc = nullptr;      // [max_batch]
-    FrameDesc* h_desc = nullptr;      // pinned
+    // per-call descriptor ring (pinned): a call whose frame sizes differ from the previous call's writes the next ring entry and
+    // uploads it in stream order; an entry is rewritten only after the upload that read it has completed (its event), so no
+    // call ever waits for the device -- a mixed-client stream (800x600 next to 416x416) used to cost a hipDeviceSynchronize
+    static constexpr int DESC_RING = 8;
+    FrameDesc* h_desc = nullptr;      // pinned [DESC_RING][max_batch]
+    hipEvent_t ev_desc[DESC_RING] = {};
+    bool desc_used[DESC_RING] = {};
+    int desc_next = 0;
     std::vector<FrameDesc> desc_cache;
     uint8_t* d_stage = nullptr;       // frame staging (host path)
     uint8_t* h_stage = nullptr;       // pinned
@@ -126,13 +139,25 @@ struct zly_engine {
     std::map<long, std::pair<bool, PairPlan>> pair_plans;   // (c, n, H, W) -> fused bottleneck tile plan (or "run unfused")
     int last_n = 0;
 
-    std::mutex mu;
+    // production phase timing: every SAMPLE_EVERY-th call of a detect path is bracketed by four timing events
+    static constexpr int SAMPLE_EVERY = 16;
+    hipEvent_t ev_t[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool t_pending = false;
+    int t_frames = 0;
+    unsigned sample_ctr = 0;
+
+    std::atomic<Ingest*> ingest{nullptr};   // created by the first zly_submit (under mu), read lock-free afterwards
+
+    std::mutex mu;                    // serialises every call that touches engine / device state
+    mutable std::mutex stats_mu;      // guards `stats` only, never held across a device call: zly_get_stats cannot wait on a batch
     zly_stats stats{};
 };
 
 namespace zly {
 
 static size_t slab_bytes_of(const zly_engine* e) { return sizeof(zly_slab_header) + (size_t)e->cfg.max_dets * sizeof(zly_det); }
+
+template <typename F> static void with_stats(zly_engine* e, F&& f) { std::lock_guard<std::mutex> lk(e->stats_mu); f(e->stats); }
 
 // ------------------------------------------------------------------------------------------------
 // plan
@@ -601,9 +626,30 @@ static int join_nms(zly_engine* e, hipStream_t s, int lag = 0)
     return ZLY_OK;
 }
 
-static int run_path(zly_engine* e, int n, const uint8_t* d_src, void* d_slabs_out, uint32_t tag0, hipStream_t s, bool with_pre, bool defer_nms = false)
+// phase timing of the last sampled call, if its events have completed: added to the stats, never waited for
+static void harvest_timing(zly_engine* e)
+{
+    if (!e->t_pending || hipEventQuery(e->ev_t[3]) != hipSuccess) return;
+    float pre = 0.f, fwd = 0.f, post = 0.f;
+    if (hipEventElapsedTime(&pre, e->ev_t[0], e->ev_t[1]) == hipSuccess && hipEventElapsedTime(&fwd, e->ev_t[1], e->ev_t[2]) == hipSuccess &&
+        hipEventElapsedTime(&post, e->ev_t[2], e->ev_t[3]) == hipSuccess) {
+        const int nf = e->t_frames;
+        with_stats(e, [&](zly_stats& st) {
+            st.sampled_frames += (uint64_t)nf;
+            st.sampled_preprocess_ms += pre; st.sampled_forward_ms += fwd; st.sampled_postprocess_ms += post > 0.f ? post : 0.f;
+        });
+    }
+    e->t_pending = false;
+}
+
+// nms_stream_out: the stream the call's NMS (its last kernel) was launched on -- `s`, or the engine's NMS stream when deferred
+static int run_path(zly_engine* e, int n, const uint8_t* d_src, void* d_slabs_out, uint32_t tag0, hipStream_t s, bool with_pre, bool defer_nms = false,
+                    hipStream_t* nms_stream_out = nullptr)
 {
     const size_t nops = e->ops.size();
+    harvest_timing(e);
+    const bool sample = with_pre && !e->t_pending && (e->sample_ctr++ % zly_engine::SAMPLE_EVERY) == 0;
+    with_stats(e, [&](zly_stats& st) { st.batches++; });
     // like the Detect side streams: below batch 16 the cross-stream edges (event record + two stream waits per call) cost
     // more than the overlap buys -- measured 0.236 -> 0.290 ms per frame at batch 1 -- so small batches stay in stream order
     defer_nms = defer_nms && e->nms_stream != nullptr && n >= 16;
@@ -623,6 +669,7 @@ static int run_path(zly_engine* e, int n, const uint8_t* d_src, void* d_slabs_ou
     // (kernels_stem.hip); zly_forward (caller-supplied fp32 images) keeps the generic model.0 conv.
     const bool fused = with_pre && e->stem_fused;
     size_t first = 1;
+    if (sample) HIP_TRY(hipEventRecord(e->ev_t[0], s), ZLY_ERR_INFERENCE);
     if (fused) {
         StemArgs st = e->stem;
         st.src = d_src; st.desc = e->d_desc;
@@ -631,6 +678,7 @@ static int run_path(zly_engine* e, int n, const uint8_t* d_src, void* d_slabs_ou
     } else if (with_pre) {
         HIP_TRY(run_op(e, e->ops[0], n, d_src, nullptr, 0, s), ZLY_ERR_INFERENCE);
     }
+    if (sample) HIP_TRY(hipEventRecord(e->ev_t[1], s), ZLY_ERR_INFERENCE);
     if (e->cfg.use_graph) {
         const int key = (n * 2 + (fused ? 1 : 0)) * 2 + par;     // the captured Detect tail holds the candidate buffer's address
         auto it = e->graphs.find(key);
@@ -651,7 +699,10 @@ static int run_path(zly_engine* e, int n, const uint8_t* d_src, void* d_slabs_ou
     } else {
         HIP_TRY(run_ops(e, first, nops - 1, n, nullptr, nullptr, 0, s), ZLY_ERR_INFERENCE);
     }
+    if (sample) HIP_TRY(hipEventRecord(e->ev_t[2], s), ZLY_ERR_INFERENCE);
+    hipStream_t ns = s;
     if (defer_nms) {
+        ns = e->nms_stream;
         HIP_TRY(hipEventRecord(e->ev_head, s), ZLY_ERR_INFERENCE);
         HIP_TRY(hipStreamWaitEvent(e->nms_stream, e->ev_head, 0), ZLY_ERR_INFERENCE);
         HIP_TRY(run_op(e, e->ops[nops - 1], n, nullptr, d_slabs_out, tag0, e->nms_stream), ZLY_ERR_INFERENCE);
@@ -660,6 +711,11 @@ static int run_path(zly_engine* e, int n, const uint8_t* d_src, void* d_slabs_ou
     } else {
         HIP_TRY(run_op(e, e->ops[nops - 1], n, nullptr, d_slabs_out, tag0, s), ZLY_ERR_INFERENCE);
     }
+    if (sample) {
+        HIP_TRY(hipEventRecord(e->ev_t[3], ns), ZLY_ERR_INFERENCE);
+        e->t_pending = true; e->t_frames = n;
+    }
+    if (nms_stream_out) *nms_stream_out = ns;
     e->last_n = n;
     return ZLY_OK;
 }
@@ -670,17 +726,23 @@ static int set_desc(zly_engine* e, int n, const int32_t* w, const int32_t* h, co
     for (int i = 0; i < n && same; ++i)
         same = e->desc_cache[(size_t)i].w == w[i] && e->desc_cache[(size_t)i].h == h[i] && e->desc_cache[(size_t)i].src_off == offs[i];
     if (same) return ZLY_OK;
-    // rare path (frame sizes changed): the pinned mirror may still be in flight from a previous call, possibly
-    // on a caller-owned stream, so wait for the whole device before rewriting it
-    HIP_TRY(hipDeviceSynchronize(), ZLY_ERR_INFERENCE);
+    // frame sizes / offsets changed: next entry of the pinned ring, uploaded in stream order.  Calls on one engine are
+    // stream-ordered by contract (they share every activation buffer), so the upload cannot overtake a kernel of the
+    // previous call that still reads d_desc; the ring entry itself is only reused once ITS upload has completed.
+    const int r = e->desc_next;
+    e->desc_next = (r + 1) % zly_engine::DESC_RING;
+    if (e->desc_used[r]) HIP_TRY(hipEventSynchronize(e->ev_desc[r]), ZLY_ERR_INFERENCE);     // 8 uploads back: long complete
+    FrameDesc* hd = e->h_desc + (size_t)r * (size_t)e->cfg.max_batch;
     if ((int)e->desc_cache.size() < n) e->desc_cache.resize((size_t)n);
     for (int i = 0; i < n; ++i) {
         FrameDesc d; d.src_off = offs[i]; d.w = w[i]; d.h = h[i];
-        e->h_desc[i] = d;
+        hd[i] = d;
         e->desc_cache[(size_t)i] = d;
     }
     for (size_t i = (size_t)n; i < e->desc_cache.size(); ++i) e->desc_cache[i].w = -1;
-    HIP_TRY(hipMemcpyAsync(e->d_desc, e->h_desc, sizeof(FrameDesc) * (size_t)n, hipMemcpyHostToDevice, s), ZLY_ERR_INFERENCE);
+    HIP_TRY(hipMemcpyAsync(e->d_desc, hd, sizeof(FrameDesc) * (size_t)n, hipMemcpyHostToDevice, s), ZLY_ERR_INFERENCE);
+    HIP_TRY(hipEventRecord(e->ev_desc[r], s), ZLY_ERR_INFERENCE);
+    e->desc_used[r] = true;
     return ZLY_OK;
 }
 
@@ -714,10 +776,13 @@ static uint64_t now_ms()
     return (uint64_t)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::system_clock::now().time_since_epoch()).count();
 }
 
+static void ingest_destroy(zly_engine* e);
+
 static void destroy_engine(zly_engine* e)
 {
     if (!e) return;
     hipSetDevice(e->dev);
+    ingest_destroy(e);
     if (e->stream) hipStreamSynchronize(e->stream);
     for (int i = 0; i < 2; ++i) if (e->side[i]) hipStreamSynchronize(e->side[i]);
     if (e->nms_stream) hipStreamSynchronize(e->nms_stream);
@@ -735,9 +800,341 @@ static void destroy_engine(zly_engine* e)
     }
     if (e->ev_head) hipEventDestroy(e->ev_head);
     for (int i = 0; i < 2; ++i) if (e->ev_nms[i]) hipEventDestroy(e->ev_nms[i]);
+    for (int i = 0; i < zly_engine::DESC_RING; ++i) if (e->ev_desc[i]) hipEventDestroy(e->ev_desc[i]);
+    for (int i = 0; i < 4; ++i) if (e->ev_t[i]) hipEventDestroy(e->ev_t[i]);
     if (e->nms_stream) hipStreamDestroy(e->nms_stream);
     if (e->stream) hipStreamDestroy(e->stream);
     delete e;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// pipelined host-to-host path: zly_submit / zly_poll / zly_wait  (include/zly.h)
+//
+//   submitting threads --memcpy--> pinned slot k+2      (host cores, in parallel)
+//   copy stream        --H2D-----> d_stage of slot k+1  (PCIe, while ...)
+//   engine stream      -- path --> slot k               (... the previous batch computes)
+//   d2h stream         --D2H-----> pinned slabs of slot k-1, completion thread wakes the waiters
+//
+// A ring slot goes FREE -> OPEN (accepting frames) -> CLOSED (no more frames; copies may still be in progress) ->
+// INFLIGHT (enqueued on the device) -> DONE (results in pinned host memory) -> FREE (every ticket consumed).  Slots are
+// used in ring order, so batch b lives in slot b % S and a ticket is (batch << 16 | index in batch).
+// ------------------------------------------------------------------------------------------------
+enum { SLOT_FREE = 0, SLOT_OPEN, SLOT_CLOSED, SLOT_INFLIGHT, SLOT_DONE };
+
+struct IngestSlot {
+    uint8_t* h_stage = nullptr; uint8_t* d_stage = nullptr;
+    unsigned char* h_slabs = nullptr; unsigned char* d_slabs = nullptr;
+    hipEvent_t ev_h2d = nullptr, ev_done = nullptr, ev_out = nullptr;
+    int state = SLOT_FREE;
+    uint64_t batch = 0;
+    int n_reserved = 0, n_committed = 0, n_consumed = 0;
+    size_t bytes_used = 0;
+    std::vector<int32_t> w, h;
+    std::vector<size_t> off;
+    std::vector<uint8_t> consumed;
+    int rc = ZLY_OK;
+    std::string err;
+    uint64_t ts_ms = 0;
+};
+
+struct Ingest {
+    std::mutex mu;
+    std::condition_variable cv_free;     // submitters waiting for a slot to open
+    std::condition_variable cv_disp;     // dispatcher: frames arrived / copies finished / a batch completed
+    std::condition_variable cv_comp;     // completion thread: a batch went in flight
+    std::condition_variable cv_done;     // waiters: a batch completed
+    std::vector<IngestSlot> slots;
+    size_t slot_bytes = 0;
+    int open = -1;                       // slot accepting frames, -1 = none
+    uint64_t next_batch = 0;             // batch number the next opened slot gets (slot = batch % S)
+    std::deque<int> closed, inflight;
+    int depth = 2;                       // batches enqueued on the device at once
+    bool stop = false;
+    std::thread dispatcher, completer;
+    hipStream_t copy_stream = nullptr, d2h_stream = nullptr;
+};
+
+static int env_int(const char* name, int fallback) { const char* v = getenv(name); return (v && *v) ? atoi(v) : fallback; }
+
+// under ing->mu: make the next ring slot the open one if it is free
+static bool ingest_try_open(zly_engine* e, Ingest* g)
+{
+    IngestSlot& sl = g->slots[(size_t)(g->next_batch % g->slots.size())];
+    if (sl.state != SLOT_FREE) return false;
+    sl.state = SLOT_OPEN; sl.batch = g->next_batch++;
+    sl.n_reserved = sl.n_committed = sl.n_consumed = 0; sl.bytes_used = 0; sl.rc = ZLY_OK; sl.err.clear();
+    std::fill(sl.consumed.begin(), sl.consumed.end(), (uint8_t)0);
+    g->open = (int)(sl.batch % g->slots.size());
+    (void)e;
+    return true;
+}
+
+static void ingest_close_open(Ingest* g)
+{
+    if (g->open < 0) return;
+    g->slots[(size_t)g->open].state = SLOT_CLOSED;
+    g->closed.push_back(g->open);
+    g->open = -1;
+}
+
+// enqueue one closed, fully copied batch: H2D on the copy stream, the path on the engine's stream, slabs back on the d2h stream
+static void ingest_enqueue(zly_engine* e, Ingest* g, IngestSlot& sl)
+{
+    std::lock_guard<std::mutex> lk(e->mu);
+    const int n = sl.n_reserved;
+    auto body = [&]() -> int {
+        HIP_TRY(hipSetDevice(e->dev), ZLY_ERR_SYSTEM);
+        HIP_TRY(hipMemcpyAsync(sl.d_stage, sl.h_stage, sl.bytes_used, hipMemcpyHostToDevice, g->copy_stream), ZLY_ERR_INFERENCE);
+        HIP_TRY(hipEventRecord(sl.ev_h2d, g->copy_stream), ZLY_ERR_INFERENCE);
+        HIP_TRY(hipStreamWaitEvent(e->stream, sl.ev_h2d, 0), ZLY_ERR_INFERENCE);
+        int rc = set_desc(e, n, sl.w.data(), sl.h.data(), sl.off.data(), e->stream);
+        if (rc != ZLY_OK) return rc;
+        hipStream_t ns = e->stream;
+        rc = run_path(e, n, sl.d_stage, sl.d_slabs, (uint32_t)(sl.batch << 16), e->stream, true, (e->cfg.flags & ZLY_FLAG_ASYNC_NMS) != 0, &ns);
+        if (rc != ZLY_OK) return rc;
+        HIP_TRY(hipEventRecord(sl.ev_done, ns), ZLY_ERR_INFERENCE);
+        HIP_TRY(hipStreamWaitEvent(g->d2h_stream, sl.ev_done, 0), ZLY_ERR_INFERENCE);
+        HIP_TRY(hipMemcpyAsync(sl.h_slabs, sl.d_slabs, slab_bytes_of(e) * (size_t)n, hipMemcpyDeviceToHost, g->d2h_stream), ZLY_ERR_INFERENCE);
+        return ZLY_OK;
+    };
+    sl.rc = body();
+    if (sl.rc != ZLY_OK) sl.err = g_last_error;
+    hipEventRecord(sl.ev_out, g->d2h_stream);          // also on failure: the completion thread must never wait forever
+}
+
+static void ingest_dispatch_loop(zly_engine* e, Ingest* g)
+{
+    hipSetDevice(e->dev);
+    std::unique_lock<std::mutex> lk(g->mu);
+    while (true) {
+        // work = a closed batch, or frames in the open batch while the device has room (no batching window: a lone frame goes at once)
+        g->cv_disp.wait(lk, [&] {
+            if (g->stop) return true;
+            if ((int)g->inflight.size() >= g->depth) return false;
+            if (!g->closed.empty()) return g->slots[(size_t)g->closed.front()].n_committed == g->slots[(size_t)g->closed.front()].n_reserved;
+            return g->open >= 0 && g->slots[(size_t)g->open].n_reserved > 0;
+        });
+        if (g->stop) return;
+        if (g->closed.empty()) {
+            ingest_close_open(g);
+            ingest_try_open(e, g);
+            g->cv_free.notify_all();
+            continue;                                  // re-evaluate: its copies may still be running
+        }
+        const int si = g->closed.front();
+        g->closed.pop_front();
+        IngestSlot& sl = g->slots[(size_t)si];
+        lk.unlock();
+        ingest_enqueue(e, g, sl);
+        lk.lock();
+        sl.state = SLOT_INFLIGHT;
+        g->inflight.push_back(si);
+        g->cv_comp.notify_one();
+    }
+}
+
+static void ingest_complete_loop(zly_engine* e, Ingest* g)
+{
+    hipSetDevice(e->dev);
+    std::unique_lock<std::mutex> lk(g->mu);
+    while (true) {
+        g->cv_comp.wait(lk, [&] { return g->stop || !g->inflight.empty(); });
+        if (g->inflight.empty()) { if (g->stop) return; continue; }
+        const int si = g->inflight.front();
+        IngestSlot& sl = g->slots[(size_t)si];
+        lk.unlock();
+        const hipError_t r = hipEventSynchronize(sl.ev_out);
+        const uint64_t ts = now_ms();                                       // onnx_engine.cpp:813-815
+        lk.lock();
+        if (r != hipSuccess && sl.rc == ZLY_OK) { sl.rc = ZLY_ERR_INFERENCE; sl.err = std::string("hipEventSynchronize: ") + hipGetErrorString(r); }
+        sl.ts_ms = ts;
+        sl.state = SLOT_DONE;
+        g->inflight.pop_front();
+        const int n = sl.n_reserved;
+        const bool ok = sl.rc == ZLY_OK;
+        with_stats(e, [&](zly_stats& st) { if (ok) st.inference_count += (uint64_t)n; else st.inference_errors += (uint64_t)n; });
+        g->cv_done.notify_all();
+        g->cv_disp.notify_one();
+    }
+}
+
+static void ingest_free(zly_engine* e, Ingest* g);
+
+// first zly_submit: allocate the ring and start the two engine-owned threads (under e->mu)
+static int ingest_start(zly_engine* e)
+{
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (e->ingest.load()) return ZLY_OK;
+    HIP_TRY(hipSetDevice(e->dev), ZLY_ERR_SYSTEM);
+    Ingest* g = new Ingest();
+    const int S = std::max(3, std::min(16, env_int("ZLY_STAGE_SLOTS", 4)));
+    const size_t frame = (size_t)e->cfg.model_w * e->cfg.model_h * 3;
+    size_t bytes = (size_t)((double)e->cfg.max_batch * (double)frame * 1.25);
+    if (bytes < (8u << 20)) bytes = 8u << 20;
+    if (env_int("ZLY_STAGE_MB", 0) > 0) bytes = (size_t)env_int("ZLY_STAGE_MB", 0) << 20;
+    g->slot_bytes = (bytes + 4095) / 4096 * 4096;
+    g->depth = std::max(1, std::min(S - 2, env_int("ZLY_INFLIGHT", 2)));
+    g->slots.resize((size_t)S);
+    bool ok = hipStreamCreateWithFlags(&g->copy_stream, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&g->d2h_stream, hipStreamNonBlocking) == hipSuccess;
+    const size_t sb = slab_bytes_of(e) * (size_t)e->cfg.max_batch;
+    for (IngestSlot& sl : g->slots) {
+        ok = ok && hipHostMalloc((void**)&sl.h_stage, g->slot_bytes, hipHostMallocDefault) == hipSuccess &&
+             hipMalloc((void**)&sl.d_stage, g->slot_bytes) == hipSuccess &&
+             hipHostMalloc((void**)&sl.h_slabs, sb, hipHostMallocDefault) == hipSuccess && hipMalloc((void**)&sl.d_slabs, sb) == hipSuccess &&
+             hipEventCreateWithFlags(&sl.ev_h2d, hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&sl.ev_out, hipEventDisableTiming) == hipSuccess;
+        if (ok) hipMemset(sl.d_slabs, 0, sb);
+        sl.w.resize((size_t)e->cfg.max_batch); sl.h.resize((size_t)e->cfg.max_batch); sl.off.resize((size_t)e->cfg.max_batch);
+        sl.consumed.resize((size_t)e->cfg.max_batch);
+    }
+    if (!ok) { ingest_free(e, g); return fail(ZLY_ERR_SYSTEM, "allocation of the staging ring failed"); }
+    g->dispatcher = std::thread(ingest_dispatch_loop, e, g);
+    g->completer = std::thread(ingest_complete_loop, e, g);
+    e->ingest.store(g);
+    return ZLY_OK;
+}
+
+static void ingest_destroy(zly_engine* e)
+{
+    Ingest* g = e->ingest.load();
+    if (!g) return;
+    {
+        std::lock_guard<std::mutex> lk(g->mu);
+        g->stop = true;
+    }
+    g->cv_disp.notify_all(); g->cv_comp.notify_all(); g->cv_free.notify_all(); g->cv_done.notify_all();
+    if (g->dispatcher.joinable()) g->dispatcher.join();
+    if (g->completer.joinable()) g->completer.join();
+    e->ingest.store(nullptr);
+    ingest_free(e, g);
+}
+
+static void ingest_free(zly_engine* e, Ingest* g)
+{
+    if (g->copy_stream) hipStreamSynchronize(g->copy_stream);
+    if (e->stream) hipStreamSynchronize(e->stream);
+    if (e->nms_stream) hipStreamSynchronize(e->nms_stream);
+    if (g->d2h_stream) hipStreamSynchronize(g->d2h_stream);
+    for (IngestSlot& sl : g->slots) {
+        if (sl.h_stage) hipHostFree(sl.h_stage);
+        if (sl.d_stage) hipFree(sl.d_stage);
+        if (sl.h_slabs) hipHostFree(sl.h_slabs);
+        if (sl.d_slabs) hipFree(sl.d_slabs);
+        if (sl.ev_h2d) hipEventDestroy(sl.ev_h2d);
+        if (sl.ev_done) hipEventDestroy(sl.ev_done);
+        if (sl.ev_out) hipEventDestroy(sl.ev_out);
+    }
+    if (g->copy_stream) hipStreamDestroy(g->copy_stream);
+    if (g->d2h_stream) hipStreamDestroy(g->d2h_stream);
+    delete g;
+}
+
+static int ingest_submit(zly_engine* e, const uint8_t* bgr, size_t nbytes, int32_t w, int32_t h, uint64_t* ticket)
+{
+    if (!bgr || w <= 0 || h <= 0 || nbytes != (size_t)w * (size_t)h * 3u) {
+        with_stats(e, [](zly_stats& st) { st.inference_errors++; });
+        return fail(ZLY_ERR_INVALID_INPUT, "Invalid image data size: expected " + std::to_string((size_t)(w > 0 ? w : 0) * (size_t)(h > 0 ? h : 0) * 3u) +
+                                               ", got " + std::to_string(nbytes));
+    }
+    if (!e->ingest.load()) {
+        int rc = ingest_start(e);
+        if (rc != ZLY_OK) return rc;
+    }
+    Ingest* g = e->ingest.load();
+    const size_t padded = (nbytes + 15) / 16 * 16;
+    if (padded > g->slot_bytes)
+        return fail(ZLY_ERR_INVALID_INPUT, "frame of " + std::to_string(nbytes) + " bytes does not fit a staging slot of " + std::to_string(g->slot_bytes) + " bytes (ZLY_STAGE_MB)");
+    IngestSlot* sl = nullptr;
+    int idx = 0;
+    size_t off = 0;
+    {
+        std::unique_lock<std::mutex> lk(g->mu);
+        while (true) {
+            if (g->stop) return fail(ZLY_ERR_NOT_INITIALIZED, "Engine not running");
+            if (g->open < 0 && !ingest_try_open(e, g)) { g->cv_free.wait(lk); continue; }     // every ring slot is busy: back-pressure
+            IngestSlot& o = g->slots[(size_t)g->open];
+            if (o.n_reserved >= e->cfg.max_batch || o.bytes_used + padded > g->slot_bytes) {   // full: the dispatcher takes it from here
+                ingest_close_open(g);
+                g->cv_disp.notify_one();
+                continue;
+            }
+            sl = &o;
+            idx = o.n_reserved++;
+            off = o.bytes_used;
+            o.bytes_used += padded;
+            o.w[(size_t)idx] = w; o.h[(size_t)idx] = h; o.off[(size_t)idx] = off;
+            *ticket = (o.batch << 16) | (uint64_t)idx;
+            if (o.n_reserved == e->cfg.max_batch) ingest_close_open(g);
+            break;
+        }
+    }
+    memcpy(sl->h_stage + off, bgr, nbytes);               // the one host copy of the request, on the caller's thread
+    {
+        std::lock_guard<std::mutex> lk(g->mu);
+        sl->n_committed++;
+    }
+    g->cv_disp.notify_one();
+    return ZLY_OK;
+}
+
+// under g->mu: the slot a ticket lives in, or null
+static IngestSlot* ingest_slot_of(Ingest* g, uint64_t ticket, int* idx)
+{
+    const uint64_t batch = ticket >> 16;
+    *idx = (int)(ticket & 0xffffu);
+    IngestSlot& sl = g->slots[(size_t)(batch % g->slots.size())];
+    if (sl.state == SLOT_FREE || sl.batch != batch || *idx >= sl.n_reserved || sl.consumed[(size_t)*idx]) return nullptr;
+    return &sl;
+}
+
+static int ingest_poll(zly_engine* e, uint64_t ticket)
+{
+    Ingest* g = e->ingest.load();
+    if (!g) return fail(ZLY_ERR_INVALID_ARGUMENT, "unknown ticket");
+    std::lock_guard<std::mutex> lk(g->mu);
+    int idx = 0;
+    IngestSlot* sl = ingest_slot_of(g, ticket, &idx);
+    if (!sl) return fail(ZLY_ERR_INVALID_ARGUMENT, "unknown or already consumed ticket");
+    return sl->state == SLOT_DONE ? ZLY_OK : ZLY_PENDING;
+}
+
+static int ingest_wait(zly_engine* e, uint64_t ticket, zly_det* out, int32_t cap, int32_t* n_out)
+{
+    Ingest* g = e->ingest.load();
+    if (!g) return fail(ZLY_ERR_INVALID_ARGUMENT, "unknown ticket");
+    std::unique_lock<std::mutex> lk(g->mu);
+    int idx = 0;
+    IngestSlot* sl = ingest_slot_of(g, ticket, &idx);
+    if (!sl) return fail(ZLY_ERR_INVALID_ARGUMENT, "unknown or already consumed ticket");
+    g->cv_done.wait(lk, [&] { return g->stop || sl->state == SLOT_DONE; });
+    if (sl->state != SLOT_DONE) return fail(ZLY_ERR_NOT_INITIALIZED, "Engine not running");
+    const int rc = sl->rc;
+    std::string err = sl->err;
+    const uint64_t ts = sl->ts_ms;
+    lk.unlock();
+    int kept = 0;
+    if (rc == ZLY_OK) {                                    // the slot cannot be recycled before this ticket is consumed below
+        const size_t sb = slab_bytes_of(e);
+        const zly_slab_header* hd = reinterpret_cast<const zly_slab_header*>(sl->h_slabs + sb * (size_t)idx);
+        const zly_det* d = reinterpret_cast<const zly_det*>(hd + 1);
+        kept = hd->n_kept;
+        int m = std::min(std::min(kept, e->cfg.max_dets), (int)cap);
+        for (int k = 0; k < m; ++k) { out[k] = d[k]; out[k].timestamp = ts; }
+    }
+    lk.lock();
+    sl->consumed[(size_t)idx] = 1;
+    if (++sl->n_consumed == sl->n_reserved) {
+        sl->state = SLOT_FREE;
+        g->cv_free.notify_all();
+        g->cv_disp.notify_one();
+    }
+    lk.unlock();
+    if (rc != ZLY_OK) return fail(rc, err);
+    *n_out = kept;
+    return ZLY_OK;
 }
 
 }  // namespace zly
@@ -805,7 +1202,9 @@ int32_t zly_create(const zly_config* cfg, zly_engine** out)
     ok = ok && hipMalloc((void**)&e->d_count, B * sizeof(int)) == hipSuccess;
     ok = ok && hipMalloc((void**)&e->d_slabs, B * slab_bytes_of(e)) == hipSuccess;
     ok = ok && hipMalloc((void**)&e->d_desc, B * sizeof(FrameDesc)) == hipSuccess;
-    ok = ok && hipHostMalloc((void**)&e->h_desc, B * sizeof(FrameDesc), hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipHostMalloc((void**)&e->h_desc, zly_engine::DESC_RING * B * sizeof(FrameDesc), hipHostMallocDefault) == hipSuccess;
+    for (int i = 0; i < zly_engine::DESC_RING && ok; ++i) ok = hipEventCreateWithFlags(&e->ev_desc[i], hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < 4 && ok; ++i) ok = hipEventCreate(&e->ev_t[i]) == hipSuccess;
     ok = ok && hipHostMalloc((void**)&e->h_slabs, B * slab_bytes_of(e), hipHostMallocDefault) == hipSuccess;
     if (!ok) { destroy_engine(e); return fail(ZLY_ERR_SYSTEM, "device allocation failed"); }
     hipMemset(e->d_slabs, 0, B * slab_bytes_of(e));
@@ -831,7 +1230,8 @@ int32_t zly_create(const zly_config* cfg, zly_engine** out)
             rc = zly_detect(e, grey.data(), fb, cfg->model_w, cfg->model_h, dets.data(), cfg->max_dets, &nd);
             if (rc != ZLY_OK) { std::string m = g_last_error; destroy_engine(e); return fail(rc, "warm-up failed: " + m); }
         }
-        e->stats = zly_stats{};
+        with_stats(e, [](zly_stats& st) { st = zly_stats{}; });
+        e->sample_ctr = 0; e->t_pending = false;
     }
     *out = e;
     return ZLY_OK;
@@ -852,7 +1252,7 @@ static int detect_host_locked(zly_engine* e, int32_t n, const uint8_t* const* bg
     size_t total = 0;
     for (int i = 0; i < n; ++i) {
         if (!bgr[i] || w[i] <= 0 || h[i] <= 0 || nbytes[i] != (size_t)w[i] * (size_t)h[i] * 3u) {
-            e->stats.inference_errors++;
+            with_stats(e, [](zly_stats& st) { st.inference_errors++; });
             return fail(ZLY_ERR_INVALID_INPUT, "Invalid image data size: expected " + std::to_string((size_t)(w[i] > 0 ? w[i] : 0) * (size_t)(h[i] > 0 ? h[i] : 0) * 3u) +
                                                    ", got " + std::to_string(nbytes[i]));
         }
@@ -867,7 +1267,7 @@ static int detect_host_locked(zly_engine* e, int32_t n, const uint8_t* const* bg
     rc = set_desc(e, n, w, h, offs.data(), e->stream);
     if (rc != ZLY_OK) return rc;
     rc = run_path(e, n, e->d_stage, nullptr, 0, e->stream, true);
-    if (rc != ZLY_OK) { e->stats.inference_errors++; return rc; }
+    if (rc != ZLY_OK) { with_stats(e, [](zly_stats& st) { st.inference_errors++; }); return rc; }
     const size_t sb = slab_bytes_of(e);
     HIP_TRY(hipMemcpyAsync(e->h_slabs, e->d_slabs, sb * (size_t)n, hipMemcpyDeviceToHost, e->stream), ZLY_ERR_INFERENCE);
     HIP_TRY(hipStreamSynchronize(e->stream), ZLY_ERR_INFERENCE);
@@ -881,7 +1281,8 @@ static int detect_host_locked(zly_engine* e, int32_t n, const uint8_t* const* bg
         for (int k = 0; k < m; ++k) { out[(size_t)i * cap + k] = d[k]; out[(size_t)i * cap + k].timestamp = ts; }
         n_out[i] = hd->n_kept;
     }
-    e->stats.inference_count += (uint64_t)n;
+    harvest_timing(e);                                                   // the stream is idle: a sampled call's events are complete
+    with_stats(e, [&](zly_stats& st) { st.inference_count += (uint64_t)n; });
     return ZLY_OK;
 }
 
@@ -893,7 +1294,8 @@ int32_t zly_detect(zly_engine* e, const uint8_t* bgr, size_t nbytes, int32_t w, 
     const auto t0 = std::chrono::steady_clock::now();
     const uint8_t* ptrs[1] = {bgr};
     int rc = detect_host_locked(e, 1, ptrs, &nbytes, &w, &h, out, cap, n_out);
-    e->stats.last_detect_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    with_stats(e, [&](zly_stats& st) { st.last_detect_ms = ms; });
     return rc;
 }
 
@@ -905,6 +1307,26 @@ int32_t zly_detect_batch(zly_engine* e, int32_t n, const uint8_t* const* bgr, co
     if (n < 1 || n > e->cfg.max_batch) return fail(ZLY_ERR_INVALID_ARGUMENT, "batch size out of range");
     std::lock_guard<std::mutex> lk(e->mu);
     return detect_host_locked(e, n, bgr, nbytes, w, h, out, cap, n_out);
+}
+
+int32_t zly_submit(zly_engine* e, const uint8_t* bgr, size_t nbytes, int32_t w, int32_t h, uint64_t* ticket)
+{
+    if (!e) return fail(ZLY_ERR_NOT_INITIALIZED, "Engine not running");
+    if (!ticket) return fail(ZLY_ERR_INVALID_ARGUMENT, "null ticket");
+    return ingest_submit(e, bgr, nbytes, w, h, ticket);
+}
+
+int32_t zly_poll(zly_engine* e, uint64_t ticket)
+{
+    if (!e) return fail(ZLY_ERR_NOT_INITIALIZED, "Engine not running");
+    return ingest_poll(e, ticket);
+}
+
+int32_t zly_wait(zly_engine* e, uint64_t ticket, zly_det* out, int32_t cap, int32_t* n_out)
+{
+    if (!e) return fail(ZLY_ERR_NOT_INITIALIZED, "Engine not running");
+    if (!out || !n_out || cap < 0) return fail(ZLY_ERR_INVALID_ARGUMENT, "null output");
+    return ingest_wait(e, ticket, out, cap, n_out);
 }
 
 int32_t zly_detect_device(zly_engine* e, int32_t n, const void* d_frames, int32_t w, int32_t h, void* d_slabs, uint32_t frame_tag0, void* stream)
@@ -921,8 +1343,8 @@ int32_t zly_detect_device(zly_engine* e, int32_t n, const void* d_frames, int32_
     int rc = set_desc(e, n, ws.data(), hs.data(), offs.data(), s);
     if (rc != ZLY_OK) return rc;
     rc = run_path(e, n, (const uint8_t*)d_frames, d_slabs, frame_tag0, s, true, (e->cfg.flags & ZLY_FLAG_ASYNC_NMS) != 0);
-    if (rc != ZLY_OK) { e->stats.inference_errors++; return rc; }
-    e->stats.inference_count += (uint64_t)n;
+    if (rc != ZLY_OK) { with_stats(e, [](zly_stats& st) { st.inference_errors++; }); return rc; }
+    with_stats(e, [&](zly_stats& st) { st.inference_count += (uint64_t)n; });
     return ZLY_OK;
 }
 
@@ -940,9 +1362,11 @@ size_t zly_slab_bytes(const zly_engine* e) { return e ? slab_bytes_of(e) : 0; }
 int32_t zly_sync(zly_engine* e)
 {
     if (!e) return fail(ZLY_ERR_NOT_INITIALIZED, "Engine not running");
+    std::lock_guard<std::mutex> lk(e->mu);
     HIP_TRY(hipSetDevice(e->dev), ZLY_ERR_SYSTEM);
     HIP_TRY(hipStreamSynchronize(e->stream), ZLY_ERR_INFERENCE);
     if (e->nms_stream) HIP_TRY(hipStreamSynchronize(e->nms_stream), ZLY_ERR_INFERENCE);
+    harvest_timing(e);
     return ZLY_OK;
 }
 
@@ -1177,9 +1601,11 @@ int32_t zly_profile_ops(zly_engine* e, int32_t n, const void* d_frames, int32_t 
     for (size_t i = 0; i < nops; ++i) {
         ms_out[i] = (float)(acc[i] / reps);
         const int k = e->ops[i].kind;
-        if (k == OP_PREPROCESS) e->stats.total_preprocess_ms += acc[i];
-        else if (k == OP_NMS) e->stats.total_postprocess_ms += acc[i];
-        else e->stats.total_forward_ms += acc[i];
+        with_stats(e, [&](zly_stats& st) {
+            if (k == OP_PREPROCESS) st.total_preprocess_ms += acc[i];
+            else if (k == OP_NMS) st.total_postprocess_ms += acc[i];
+            else st.total_forward_ms += acc[i];
+        });
     }
     e->last_n = n;
     return ZLY_OK;
@@ -1188,6 +1614,7 @@ int32_t zly_profile_ops(zly_engine* e, int32_t n, const void* d_frames, int32_t 
 int32_t zly_get_stats(const zly_engine* e, zly_stats* out)
 {
     if (!e || !out) return fail(ZLY_ERR_INVALID_ARGUMENT, "bad argument");
+    std::lock_guard<std::mutex> lk(e->stats_mu);           // never held across a device call: does not wait on a running batch
     *out = e->stats;
     return ZLY_OK;
 }

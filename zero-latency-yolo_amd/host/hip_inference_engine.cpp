@@ -38,9 +38,17 @@ int envInt(const char* name, int fallback)
 }
 }  // namespace
 
+struct HipInferenceEngine::EngineHandle {
+    zly_engine* e = nullptr;
+    explicit EngineHandle(zly_engine* p) : e(p) {}
+    ~EngineHandle() { if (e) zly_destroy(e); }
+    EngineHandle(const EngineHandle&) = delete;
+    EngineHandle& operator=(const EngineHandle&) = delete;
+};
+
 HipInferenceEngine::HipInferenceEngine(const ServerConfig& config) : config_(config)
 {
-    max_batch_ = std::max(1, envInt("ZLY_MAX_BATCH", 8));
+    max_batch_ = std::max(1, std::min(65535, envInt("ZLY_MAX_BATCH", 64)));
     max_dets_ = std::max(1, envInt("ZLY_MAX_DETS", 256));
 }
 
@@ -52,33 +60,36 @@ Result<void> HipInferenceEngine::initialize()
     const int ndev = std::max(1, envInt("ZLY_NUM_DEVICES", 1));
     const int dev0 = std::max(0, envInt("ZLY_FIRST_DEVICE", 0));
     first_device_ = dev0;
+    std::vector<std::shared_ptr<EngineHandle>> fresh;
     for (int d = 0; d < ndev; ++d) {
         int32_t rc = ZLY_OK;
         std::string msg;
-        zly_engine* e = createEngineOn(dev0 + d, &rc, &msg);
-        if (!e) {
-            for (zly_engine* p : engines_) zly_destroy(p);
-            engines_.clear();
-            engine_mutex_.clear();
-            return Result<void>::error(toErrorCode(rc), "Failed to initialize HIP inference engine: " + msg);
-        }
-        engines_.push_back(e);
-        engine_mutex_.emplace_back(new std::mutex);
+        auto e = createEngineOn(dev0 + d, &rc, &msg);
+        if (!e) return Result<void>::error(toErrorCode(rc), "Failed to initialize HIP inference engine: " + msg);
+        fresh.push_back(std::move(e));
+    }
+    {
+        std::lock_guard<std::mutex> lk(engines_mutex_);
+        engines_ = std::move(fresh);
     }
     {
         std::lock_guard<std::mutex> lk(stats_mutex_);
         model_hash_ = sha256File(config_.model_path);
     }
     model_version_ = 1;
+    {
+        std::lock_guard<std::mutex> lk(queue_mutex_);
+        pending_.clear();                                      // nothing of a previous run may be emitted under the new sequence numbers
+        next_seq_ = 0;
+        next_done_ = 0;
+    }
     running_ = true;
-    next_seq_ = 0;
-    next_emit_ = 0;
-    for (int d = 0; d < ndev; ++d) workers_.emplace_back(&HipInferenceEngine::workerLoop, this, d);
+    completer_ = std::thread(&HipInferenceEngine::completionLoop, this);
     if (envInt("ZLY_MODEL_WATCH_MS", 10000) > 0) monitor_ = std::thread(&HipInferenceEngine::monitorLoop, this);
     return Result<void>::ok();
 }
 
-zly_engine* HipInferenceEngine::createEngineOn(int device, int32_t* rc, std::string* msg) const
+std::shared_ptr<HipInferenceEngine::EngineHandle> HipInferenceEngine::createEngineOn(int device, int32_t* rc, std::string* msg) const
 {
     zly_config c;
     zly_default_config(&c);
@@ -93,40 +104,39 @@ zly_engine* HipInferenceEngine::createEngineOn(int device, int32_t* rc, std::str
     c.dtype = envInt("ZLY_FP32", 0) ? ZLY_DTYPE_FP32 : ZLY_DTYPE_BF16;
     c.warmup_runs = 3;                                   // onnx_engine.cpp:919-954
     c.use_graph = 1;
-    c.flags = ZLY_FLAG_NO_HEAD_TENSOR;                   // the server only consumes detections
+    c.flags = ZLY_FLAG_NO_HEAD_TENSOR | ZLY_FLAG_ASYNC_NMS;   // the server only consumes detections; NMS of a batch runs beside the next one
     zly_engine* e = nullptr;
     *rc = zly_create(&c, &e);
     if (*rc != ZLY_OK) { *msg = zly_last_error(); return nullptr; }
-    return e;
+    return std::make_shared<EngineHandle>(e);
 }
 
 // Build the new engines first (hundreds of milliseconds: weight repack, upload, warm-up, beside the running ones), then
-// swap each one in while its worker is between two batches.  Any failure leaves the running model untouched.
+// swap the handles: requests submitted from then on go to the new model, requests already in flight finish on the old
+// engine, which is destroyed with its last pending request.  Any failure leaves the running model untouched.
 Result<void> HipInferenceEngine::reloadModel()
 {
     if (!running_) return Result<void>::error(ErrorCode::NOT_INITIALIZED, "Engine not running");
     std::lock_guard<std::mutex> rl(reload_mutex_);
     const std::string hash = sha256File(config_.model_path);
-    std::vector<zly_engine*> fresh;
-    for (size_t d = 0; d < engines_.size(); ++d) {
+    size_t count;
+    {
+        std::lock_guard<std::mutex> lk(engines_mutex_);
+        count = engines_.size();
+    }
+    std::vector<std::shared_ptr<EngineHandle>> fresh;
+    for (size_t d = 0; d < count; ++d) {
         int32_t rc = ZLY_OK;
         std::string msg;
-        zly_engine* e = createEngineOn(first_device_ + (int)d, &rc, &msg);
-        if (!e) {
-            for (zly_engine* p : fresh) zly_destroy(p);
-            return Result<void>::error(toErrorCode(rc), "Failed to reload model: " + msg);
-        }
-        fresh.push_back(e);
+        auto e = createEngineOn(first_device_ + (int)d, &rc, &msg);
+        if (!e) return Result<void>::error(toErrorCode(rc), "Failed to reload model: " + msg);
+        fresh.push_back(std::move(e));
     }
-    for (size_t d = 0; d < engines_.size(); ++d) {
-        zly_engine* old = nullptr;
-        {
-            std::lock_guard<std::mutex> el(*engine_mutex_[d]);
-            old = engines_[d];
-            engines_[d] = fresh[d];
-        }
-        zly_destroy(old);
+    {
+        std::lock_guard<std::mutex> lk(engines_mutex_);
+        engines_.swap(fresh);
     }
+    fresh.clear();                                              // old engines go when their last pending request is done
     {
         std::lock_guard<std::mutex> lk(stats_mutex_);
         model_hash_ = hash;
@@ -170,28 +180,47 @@ Result<void> HipInferenceEngine::shutdown()
         std::lock_guard<std::mutex> lk(queue_mutex_);
         queue_cv_.notify_all();
     }
-    for (std::thread& t : workers_)
-        if (t.joinable()) t.join();
-    workers_.clear();
+    if (completer_.joinable()) completer_.join();               // hands over what is already on the device, then stops
     if (monitor_.joinable()) monitor_.join();
-    for (zly_engine* e : engines_) zly_destroy(e);
-    engines_.clear();
-    engine_mutex_.clear();
     {
         std::lock_guard<std::mutex> lk(queue_mutex_);
-        dropped_frames_ += queue_.size();
-        queue_.clear();
+        dropped_frames_ += pending_.size();
+        pending_.clear();                                       // stale results must never be emitted by a later initialize()
     }
+    std::vector<std::shared_ptr<EngineHandle>> old;
+    {
+        std::lock_guard<std::mutex> lk(engines_mutex_);
+        old.swap(engines_);
+    }
+    old.clear();
     return Result<void>::ok();
 }
 
+// Runs on the caller's thread (the UDP receive thread in the reference's server, network_server.cpp:209): the request's
+// pixels are copied ONCE, into the engine's pinned staging ring; nothing of `request` is retained.
 Result<void> HipInferenceEngine::submitInference(const InferenceRequest& request)
 {
     if (!running_) return Result<void>::error(ErrorCode::NOT_INITIALIZED, "Engine not running");
+    const uint64_t seq = next_seq_.fetch_add(1);
+    Pending p;
+    p.client_id = request.client_id; p.frame_id = request.frame_id; p.timestamp = request.timestamp;
+    p.enqueue_ms = wallMs();
+    {
+        std::lock_guard<std::mutex> lk(engines_mutex_);
+        if (!engines_.empty()) p.engine = engines_[(size_t)(seq % engines_.size())];        // one-frame-per-GPU round robin
+    }
+    if (!p.engine) {
+        p.failed = true;
+    } else {
+        // a request with the wrong byte count fails alone (INVALID_INPUT, onnx_engine.cpp:659-665): counted, no callback
+        const int32_t rc = zly_submit(p.engine->e, request.data.data(), request.data.size(), request.width, request.height, &p.ticket);
+        if (rc != ZLY_OK) { p.failed = true; p.engine.reset(); }
+    }
+    if (p.failed) inference_errors_++;
     {
         std::lock_guard<std::mutex> lk(queue_mutex_);
-        queue_.push_back(Pending{next_seq_++, request, wallMs()});       // copies the pixels: the caller's request is not retained
-        if (queue_.size() > queue_high_water_mark_) queue_high_water_mark_ = queue_.size();
+        pending_.emplace(seq, std::move(p));
+        if (pending_.size() > queue_high_water_mark_) queue_high_water_mark_ = pending_.size();
     }
     queue_cv_.notify_one();
     return Result<void>::ok();
@@ -199,104 +228,64 @@ Result<void> HipInferenceEngine::submitInference(const InferenceRequest& request
 
 void HipInferenceEngine::setCallback(InferenceCallback callback)
 {
-    std::lock_guard<std::mutex> lk(emit_mutex_);
+    std::lock_guard<std::mutex> lk(queue_mutex_);
     callback_ = std::move(callback);
 }
 
 size_t HipInferenceEngine::getQueueSize() const
 {
     std::lock_guard<std::mutex> lk(queue_mutex_);
-    return queue_.size();
+    return pending_.size();
 }
 
 std::string HipInferenceEngine::getName() const { return "hip"; }
 
-void HipInferenceEngine::workerLoop(int worker)
+// One engine-owned thread hands results to the callback in submission order (reference: the inference thread,
+// onnx_engine.cpp:355-364); several GPUs finishing out of order are re-ordered by the sequence number.
+void HipInferenceEngine::completionLoop()
 {
-    std::vector<Pending> batch;
-    std::vector<const uint8_t*> ptrs;
-    std::vector<size_t> nbytes;
-    std::vector<int32_t> ws, hs, n_out;
-    std::vector<zly_det> dets((size_t)max_batch_ * max_dets_);
+    std::vector<zly_det> dets((size_t)max_dets_);
+    int idle_rounds = 0;
     while (true) {
-        batch.clear();
+        Pending p;
+        InferenceCallback cb;
         {
             std::unique_lock<std::mutex> lk(queue_mutex_);
-            queue_cv_.wait(lk, [&] { return !running_ || !queue_.empty(); });
-            if (!running_) return;
-            // take whatever is pending, up to one batch: no batching window, so a lone request is
-            // served at single-frame latency and a backlog is served at batch throughput
-            while (!queue_.empty() && (int)batch.size() < max_batch_) {
-                batch.push_back(std::move(queue_.front()));
-                queue_.pop_front();
+            const bool have = queue_cv_.wait_for(lk, std::chrono::milliseconds(100), [&] { return pending_.count(next_done_) != 0; });
+            if (!have) {
+                // shutting down: what is pending is still delivered; a sequence number that never arrives (a submitter that
+                // lost the race with shutdown) must not hold the thread for ever
+                if (!running_ && (pending_.empty() || ++idle_rounds > 20)) return;
+                continue;
             }
+            idle_rounds = 0;
+            auto it = pending_.find(next_done_);
+            p = std::move(it->second);
+            pending_.erase(it);
+            ++next_done_;
+            cb = callback_;
         }
-        const int n = (int)batch.size();
-        std::vector<std::pair<uint64_t, Done>> finished;
-        finished.reserve((size_t)n);
-        // a request with the wrong byte count fails alone (INVALID_INPUT, onnx_engine.cpp:659-665)
-        std::vector<int> good;
-        for (int i = 0; i < n; ++i) {
-            const InferenceRequest& r = batch[(size_t)i].request;
-            if (r.width == 0 || r.height == 0 || r.data.size() != (size_t)r.width * r.height * 3u) {
-                inference_errors_++;
-                finished.emplace_back(batch[(size_t)i].seq, Done{r.client_id, false, GameState{}});
-            } else {
-                good.push_back(i);
-            }
+        if (p.failed) continue;
+        int32_t n = 0;
+        const int32_t rc = zly_wait(p.engine->e, p.ticket, dets.data(), max_dets_, &n);
+        if (rc != ZLY_OK) { inference_errors_++; continue; }    // not invoked on error results (onnx_engine.cpp:380-388)
+        GameState st;
+        st.frame_id = p.frame_id;                                // onnx_engine.cpp:520-521
+        st.timestamp = p.timestamp;
+        const int cnt = std::min<int>(n, max_dets_);
+        st.detections.resize((size_t)cnt);
+        static_assert(sizeof(zly_det) == sizeof(Detection), "zly_det must be layout-identical to Detection");
+        if (cnt) std::memcpy(st.detections.data(), dets.data(), (size_t)cnt * sizeof(Detection));
+        inference_count_++;
+        {
+            std::lock_guard<std::mutex> lk(stats_mutex_);
+            const double lat = (double)(wallMs() - p.enqueue_ms);
+            latency_window_ms_.push_back(lat);
+            if (latency_window_ms_.size() > 100) latency_window_ms_.pop_front();
+            total_latency_ms_ += lat;
         }
-        if (!good.empty()) {
-            const int m = (int)good.size();
-            ptrs.resize((size_t)m); nbytes.resize((size_t)m); ws.resize((size_t)m); hs.resize((size_t)m); n_out.assign((size_t)m, 0);
-            for (int k = 0; k < m; ++k) {
-                const InferenceRequest& r = batch[(size_t)good[(size_t)k]].request;
-                ptrs[(size_t)k] = r.data.data(); nbytes[(size_t)k] = r.data.size(); ws[(size_t)k] = r.width; hs[(size_t)k] = r.height;
-            }
-            int32_t rc;
-            {
-                std::lock_guard<std::mutex> el(*engine_mutex_[(size_t)worker]);      // a reload swaps the handle between two batches
-                rc = zly_detect_batch(engines_[(size_t)worker], m, ptrs.data(), nbytes.data(), ws.data(), hs.data(), dets.data(), max_dets_, n_out.data());
-            }
-            batches_++;
-            const uint64_t done_ms = wallMs();
-            for (int k = 0; k < m; ++k) {
-                const Pending& p = batch[(size_t)good[(size_t)k]];
-                Done d;
-                d.client_id = p.request.client_id;
-                d.ok = rc == ZLY_OK;
-                if (d.ok) {
-                    d.state.frame_id = p.request.frame_id;                 // onnx_engine.cpp:520-521
-                    d.state.timestamp = p.request.timestamp;
-                    const int cnt = std::min<int>(n_out[(size_t)k], max_dets_);
-                    d.state.detections.resize((size_t)cnt);
-                    static_assert(sizeof(zly_det) == sizeof(Detection), "zly_det must be layout-identical to Detection");
-                    if (cnt) std::memcpy(d.state.detections.data(), dets.data() + (size_t)k * max_dets_, (size_t)cnt * sizeof(Detection));
-                    inference_count_++;
-                    std::lock_guard<std::mutex> lk(stats_mutex_);
-                    const double lat = (double)(done_ms - p.enqueue_ms);
-                    latency_window_ms_.push_back(lat);
-                    if (latency_window_ms_.size() > 100) latency_window_ms_.pop_front();
-                    total_latency_ms_ += lat;
-                } else {
-                    inference_errors_++;
-                }
-                finished.emplace_back(p.seq, std::move(d));
-            }
-        }
-        emitInOrder(std::move(finished));
-    }
-}
-
-// Callbacks fire in submission order even when several GPUs finish out of order.
-void HipInferenceEngine::emitInOrder(std::vector<std::pair<uint64_t, Done>>&& finished)
-{
-    std::lock_guard<std::mutex> lk(emit_mutex_);
-    for (auto& f : finished) finished_.emplace(f.first, std::move(f.second));
-    while (!finished_.empty() && finished_.begin()->first == next_emit_) {
-        Done& d = finished_.begin()->second;
-        if (d.ok && callback_) callback_(d.client_id, d.state);             // not invoked on error results (:380-388)
-        finished_.erase(finished_.begin());
-        ++next_emit_;
+        p.engine.reset();                                        // an engine replaced by a reload goes with its last request
+        if (cb) cb(p.client_id, st);
     }
 }
 
@@ -317,7 +306,6 @@ std::unordered_map<std::string, std::string> HipInferenceEngine::getStatus() con
     s["inference_errors"] = std::to_string(inference_errors_.load());
     s["dropped_frames"] = std::to_string(dropped_frames_.load());
     s["dynamic_batching"] = "enabled";
-    s["batches"] = std::to_string(batches_.load());
     double avg = 0, p99 = 0;
     {
         std::lock_guard<std::mutex> lk(stats_mutex_);
@@ -331,21 +319,27 @@ std::unordered_map<std::string, std::string> HipInferenceEngine::getStatus() con
     }
     s["avg_inference_time_ms"] = std::to_string(avg);
     s["p99_inference_time_ms"] = std::to_string(p99);
-    zly_stats st{};
-    bool have = false;
-    if (!engines_.empty() && !engine_mutex_.empty()) {
-        std::lock_guard<std::mutex> el(*engine_mutex_[0]);          // the handle may be swapped by a reload
-        have = zly_get_stats(engines_[0], &st) == ZLY_OK;
+    // per-phase device time, sampled by the engine on every 16th batch (the reference accumulates its three phase
+    // timers per frame, onnx_engine.cpp:530-557,605-618).  zly_get_stats never waits on a running batch.
+    std::vector<std::shared_ptr<EngineHandle>> engines;
+    {
+        std::lock_guard<std::mutex> lk(engines_mutex_);
+        engines = engines_;
     }
-    if (have && st.inference_count > 0) {
-        s["avg_preprocessing_time_ms"] = std::to_string(st.total_preprocess_ms / (double)st.inference_count);
-        s["avg_postprocessing_time_ms"] = std::to_string(st.total_postprocess_ms / (double)st.inference_count);
-    } else {
-        s["avg_preprocessing_time_ms"] = "0";
-        s["avg_postprocessing_time_ms"] = "0";
+    uint64_t frames = 0, batches = 0;
+    double pre = 0, fwd = 0, post = 0;
+    for (const auto& h : engines) {
+        zly_stats st{};
+        if (zly_get_stats(h->e, &st) != ZLY_OK) continue;
+        frames += st.sampled_frames; batches += st.batches;
+        pre += st.sampled_preprocess_ms; fwd += st.sampled_forward_ms; post += st.sampled_postprocess_ms;
     }
-    s["worker_threads"] = std::to_string(workers_.size());
-    s["devices"] = std::to_string(engines_.size());
+    s["batches"] = std::to_string(batches);
+    s["avg_preprocessing_time_ms"] = frames ? std::to_string(pre / (double)frames) : "0";
+    s["avg_forward_time_ms"] = frames ? std::to_string(fwd / (double)frames) : "0";
+    s["avg_postprocessing_time_ms"] = frames ? std::to_string(post / (double)frames) : "0";
+    s["worker_threads"] = std::to_string(engines.size());
+    s["devices"] = std::to_string(engines.size());
     return s;
 }
 

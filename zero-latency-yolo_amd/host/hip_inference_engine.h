@@ -19,11 +19,13 @@
 // Deliberate differences (DESIGN.md "host side"):
 //   * every successful frame reaches the callback, in submission order (the reference drops frames
 //     popped by its worker threads, :459-460);
-//   * pending requests are batched into ONE zly_detect_batch call (the reference's "dynamic batching"
-//     is a TODO that runs frames one by one, :348-365) -- no batching window, so no added latency;
+//   * submitInference copies the request's pixels ONCE, straight into the engine's pinned staging ring, on the
+//     caller's thread (zly_submit); the engine batches whatever is pending -- no batching window, so no added latency --
+//     and overlaps upload, compute and download of consecutive batches (the reference's "dynamic batching" is a TODO
+//     that runs frames one by one, :348-365).  One completion thread hands results to the callback (zly_wait);
 //   * no simulation mode: a missing/bad model file is an error from initialize(), not random boxes
 //     (:70-75,105-110);
-//   * one worker thread per GPU (ZLY_NUM_DEVICES, default 1) instead of CPU worker threads.
+//   * one engine per GPU (ZLY_NUM_DEVICES, default 1; requests go round robin) instead of CPU worker threads.
 #pragma once
 
 #include "zly_compat.hpp"
@@ -31,7 +33,10 @@
 #include <atomic>
 #include <condition_variable>
 #include <deque>
+#include <map>
+#include <memory>
 #include <mutex>
+#include <thread>
 
 struct zly_engine;
 
@@ -54,38 +59,39 @@ public:
     Result<void> reloadModel();
 
 private:
-    struct Pending { uint64_t seq; InferenceRequest request; uint64_t enqueue_ms; };
-    struct Done { uint32_t client_id; bool ok; GameState state; };
+    struct EngineHandle;                                   // owns a zly_engine*; destroyed with its last pending request
+    struct Pending {
+        std::shared_ptr<EngineHandle> engine;
+        uint64_t ticket = 0;
+        bool failed = false;                               // refused by zly_submit (wrong byte count): no callback, keeps the sequence dense
+        uint32_t client_id = 0, frame_id = 0;
+        uint64_t timestamp = 0, enqueue_ms = 0;
+    };
 
-    void workerLoop(int worker);
+    void completionLoop();
     void monitorLoop();
-    zly_engine* createEngineOn(int device, int32_t* rc, std::string* msg) const;
-    void emitInOrder(std::vector<std::pair<uint64_t, Done>>&& finished);
+    std::shared_ptr<EngineHandle> createEngineOn(int device, int32_t* rc, std::string* msg) const;
 
     ServerConfig config_;
-    int max_batch_ = 8;
+    int max_batch_ = 64;
     int max_dets_ = 256;
-    std::vector<zly_engine*> engines_;          // one per GPU
-    std::vector<std::unique_ptr<std::mutex>> engine_mutex_;   // held by a worker for the duration of a batch; by reloadModel to swap
+    mutable std::mutex engines_mutex_;                     // guards the vector (held for pointer copies only, never across a device call)
+    std::vector<std::shared_ptr<EngineHandle>> engines_;   // one per GPU
     int first_device_ = 0;
-    std::thread monitor_;
-    std::mutex reload_mutex_;                   // one reload at a time
+    std::thread monitor_, completer_;
+    std::mutex reload_mutex_;                              // one reload at a time
     std::atomic<uint32_t> model_version_{1};
-    std::string model_hash_;                    // guarded by stats_mutex_
-    std::vector<std::thread> workers_;
+    std::string model_hash_;                               // guarded by stats_mutex_
     std::atomic<bool> running_{false};
 
-    mutable std::mutex queue_mutex_;
+    mutable std::mutex queue_mutex_;                       // pending_, next_seq_, next_done_, callback_
     std::condition_variable queue_cv_;
-    std::deque<Pending> queue_;
-    uint64_t next_seq_ = 0;
-
-    std::mutex emit_mutex_;
-    std::map<uint64_t, Done> finished_;
-    uint64_t next_emit_ = 0;
+    std::map<uint64_t, Pending> pending_;                  // submitted, not yet handed to the callback; keyed by submission sequence
+    std::atomic<uint64_t> next_seq_{0};
+    uint64_t next_done_ = 0;
     InferenceCallback callback_;
 
-    std::atomic<uint64_t> inference_count_{0}, inference_errors_{0}, dropped_frames_{0}, batches_{0};
+    std::atomic<uint64_t> inference_count_{0}, inference_errors_{0}, dropped_frames_{0};
     std::atomic<size_t> queue_high_water_mark_{0};
     mutable std::mutex stats_mutex_;
     std::deque<double> latency_window_ms_;      // last 100 request latencies (onnx_engine.cpp:428-449)

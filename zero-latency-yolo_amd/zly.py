@@ -23,6 +23,7 @@ ERR_MODEL_NOT_FOUND = 201
 ERR_MODEL_LOAD = 202
 ERR_INVALID_INPUT = 203
 ERR_SYSTEM = 300
+PENDING = 1
 DTYPE_FP32, DTYPE_BF16 = 0, 1
 SLAB_OVERFLOW = 1
 FLAG_DUMP_LOGITS = 1
@@ -33,7 +34,7 @@ FLAG_ASYNC_NMS = 8
 # every symbol include/zly.h declares (tests/test_abi.py checks the library exports them all)
 SYMBOLS = [
     "zly_default_config", "zly_create", "zly_destroy", "zly_last_error", "zly_version",
-    "zly_detect", "zly_detect_batch", "zly_detect_device", "zly_slab_bytes", "zly_read_slabs", "zly_sync", "zly_join",
+    "zly_detect", "zly_detect_batch", "zly_submit", "zly_poll", "zly_wait", "zly_detect_device", "zly_slab_bytes", "zly_read_slabs", "zly_sync", "zly_join",
     "zly_preprocess", "zly_forward", "zly_head_tensor", "zly_postprocess", "zly_debug_tap",
     "zly_num_classes", "zly_num_anchors", "zly_num_ops", "zly_op_info_at", "zly_profile_ops", "zly_get_stats",
 ]
@@ -54,7 +55,9 @@ class Config(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("inference_count", C.c_uint64), ("inference_errors", C.c_uint64),
                 ("total_preprocess_ms", C.c_double), ("total_forward_ms", C.c_double),
-                ("total_postprocess_ms", C.c_double), ("last_detect_ms", C.c_double)]
+                ("total_postprocess_ms", C.c_double), ("last_detect_ms", C.c_double),
+                ("sampled_frames", C.c_uint64), ("sampled_preprocess_ms", C.c_double), ("sampled_forward_ms", C.c_double),
+                ("sampled_postprocess_ms", C.c_double), ("batches", C.c_uint64)]
 
 
 class OpInfo(C.Structure):
@@ -90,6 +93,9 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.zly_version.argtypes = []; lib.zly_version.restype = C.c_char_p
     lib.zly_detect.argtypes = [vp, vp, sz, i32, i32, vp, i32, pi32]; lib.zly_detect.restype = i32
     lib.zly_detect_batch.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(sz), pi32, pi32, vp, i32, pi32]; lib.zly_detect_batch.restype = i32
+    lib.zly_submit.argtypes = [vp, vp, sz, i32, i32, C.POINTER(C.c_uint64)]; lib.zly_submit.restype = i32
+    lib.zly_poll.argtypes = [vp, C.c_uint64]; lib.zly_poll.restype = i32
+    lib.zly_wait.argtypes = [vp, C.c_uint64, vp, i32, pi32]; lib.zly_wait.restype = i32
     lib.zly_detect_device.argtypes = [vp, i32, vp, i32, i32, vp, u32, vp]; lib.zly_detect_device.restype = i32
     lib.zly_slab_bytes.argtypes = [vp]; lib.zly_slab_bytes.restype = sz
     lib.zly_read_slabs.argtypes = [vp, i32, vp]; lib.zly_read_slabs.restype = i32
@@ -179,6 +185,27 @@ class Engine:
         n_out = (C.c_int32 * n)()
         _check(self.lib, self.lib.zly_detect_batch(self.h, n, ptrs, nbytes, ws, hs, out.ctypes.data, cap, n_out))
         return [(out[i, :min(n_out[i], cap)], int(n_out[i])) for i in range(n)]
+
+    # -- asynchronous, pipelined host-to-host path ---------------------------------------------------
+    def submit(self, frame: np.ndarray, nbytes: Optional[int] = None) -> int:
+        """copies the frame into the engine's pinned staging ring (on this thread) and returns a ticket"""
+        t = C.c_uint64(0)
+        _check(self.lib, self.lib.zly_submit(self.h, frame.ctypes.data, frame.nbytes if nbytes is None else nbytes,
+                                             frame.shape[1], frame.shape[0], C.byref(t)))
+        return t.value
+
+    def poll(self, ticket: int) -> bool:
+        rc = self.lib.zly_poll(self.h, ticket)
+        if rc not in (OK, PENDING):
+            _check(self.lib, rc)
+        return rc == OK
+
+    def wait(self, ticket: int, cap: Optional[int] = None) -> Tuple[np.ndarray, int]:
+        cap = cap or self.max_dets
+        out = np.zeros(cap, dtype=DET_DTYPE)
+        n = C.c_int32(0)
+        _check(self.lib, self.lib.zly_wait(self.h, ticket, out.ctypes.data, cap, C.byref(n)))
+        return out[:min(n.value, cap)], n.value
 
     def detect_device(self, d_frames_ptr: int, n: int, w: int, h: int, d_slabs_ptr: int = 0, tag0: int = 0, stream: int = 0):
         _check(self.lib, self.lib.zly_detect_device(self.h, n, d_frames_ptr, w, h, d_slabs_ptr or None, tag0, stream or None))
