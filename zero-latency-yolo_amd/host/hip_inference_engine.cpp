@@ -80,8 +80,9 @@ Result<void> HipInferenceEngine::initialize()
     {
         std::lock_guard<std::mutex> lk(queue_mutex_);
         pending_.clear();                                      // nothing of a previous run may be emitted under the new sequence numbers
+        finished_.clear();
         next_seq_ = 0;
-        next_done_ = 0;
+        next_emit_ = 0;
     }
     running_ = true;
     completer_ = std::thread(&HipInferenceEngine::completionLoop, this);
@@ -186,6 +187,7 @@ Result<void> HipInferenceEngine::shutdown()
         std::lock_guard<std::mutex> lk(queue_mutex_);
         dropped_frames_ += pending_.size();
         pending_.clear();                                       // stale results must never be emitted by a later initialize()
+        finished_.clear();
     }
     std::vector<std::shared_ptr<EngineHandle>> old;
     {
@@ -203,6 +205,7 @@ Result<void> HipInferenceEngine::submitInference(const InferenceRequest& request
     if (!running_) return Result<void>::error(ErrorCode::NOT_INITIALIZED, "Engine not running");
     const uint64_t seq = next_seq_.fetch_add(1);
     Pending p;
+    p.seq = seq;
     p.client_id = request.client_id; p.frame_id = request.frame_id; p.timestamp = request.timestamp;
     p.enqueue_ms = wallMs();
     {
@@ -219,8 +222,8 @@ Result<void> HipInferenceEngine::submitInference(const InferenceRequest& request
     if (p.failed) inference_errors_++;
     {
         std::lock_guard<std::mutex> lk(queue_mutex_);
-        pending_.emplace(seq, std::move(p));
-        if (pending_.size() > queue_high_water_mark_) queue_high_water_mark_ = pending_.size();
+        pending_.push_back(std::move(p));
+        if (pending_.size() + finished_.size() > queue_high_water_mark_) queue_high_water_mark_ = pending_.size() + finished_.size();
     }
     queue_cv_.notify_one();
     return Result<void>::ok();
@@ -235,7 +238,7 @@ void HipInferenceEngine::setCallback(InferenceCallback callback)
 size_t HipInferenceEngine::getQueueSize() const
 {
     std::lock_guard<std::mutex> lk(queue_mutex_);
-    return pending_.size();
+    return pending_.size() + finished_.size();
 }
 
 std::string HipInferenceEngine::getName() const { return "hip"; }
@@ -245,47 +248,61 @@ std::string HipInferenceEngine::getName() const { return "hip"; }
 void HipInferenceEngine::completionLoop()
 {
     std::vector<zly_det> dets((size_t)max_dets_);
-    int idle_rounds = 0;
     while (true) {
         Pending p;
-        InferenceCallback cb;
         {
             std::unique_lock<std::mutex> lk(queue_mutex_);
-            const bool have = queue_cv_.wait_for(lk, std::chrono::milliseconds(100), [&] { return pending_.count(next_done_) != 0; });
-            if (!have) {
-                // shutting down: what is pending is still delivered; a sequence number that never arrives (a submitter that
-                // lost the race with shutdown) must not hold the thread for ever
-                if (!running_ && (pending_.empty() || ++idle_rounds > 20)) return;
+            queue_cv_.wait_for(lk, std::chrono::milliseconds(100), [&] { return !pending_.empty() || !running_; });
+            if (pending_.empty()) {
+                if (!running_) return;                           // shutting down: everything already in the ring has been handed over
                 continue;
             }
-            idle_rounds = 0;
-            auto it = pending_.find(next_done_);
-            p = std::move(it->second);
-            pending_.erase(it);
-            ++next_done_;
+            p = std::move(pending_.front());
+            pending_.pop_front();
+        }
+        Done d;
+        d.client_id = p.client_id; d.enqueue_ms = p.enqueue_ms;
+        if (!p.failed) {
+            int32_t n = 0;
+            const int32_t rc = zly_wait(p.engine->e, p.ticket, dets.data(), max_dets_, &n);
+            if (rc == ZLY_OK) {
+                d.ok = true;
+                d.state.frame_id = p.frame_id;                   // onnx_engine.cpp:520-521
+                d.state.timestamp = p.timestamp;
+                const int cnt = std::min<int>(n, max_dets_);
+                d.state.detections.resize((size_t)cnt);
+                static_assert(sizeof(zly_det) == sizeof(Detection), "zly_det must be layout-identical to Detection");
+                if (cnt) std::memcpy(d.state.detections.data(), dets.data(), (size_t)cnt * sizeof(Detection));
+            } else {
+                inference_errors_++;
+            }
+            p.engine.reset();                                    // an engine replaced by a reload goes with its last request
+        }
+        // hand over in submission order
+        std::vector<Done> ready;
+        InferenceCallback cb;
+        {
+            std::lock_guard<std::mutex> lk(queue_mutex_);
+            finished_.emplace(p.seq, std::move(d));
+            while (!finished_.empty() && finished_.begin()->first == next_emit_) {
+                ready.push_back(std::move(finished_.begin()->second));
+                finished_.erase(finished_.begin());
+                ++next_emit_;
+            }
             cb = callback_;
         }
-        if (p.failed) continue;
-        int32_t n = 0;
-        const int32_t rc = zly_wait(p.engine->e, p.ticket, dets.data(), max_dets_, &n);
-        if (rc != ZLY_OK) { inference_errors_++; continue; }    // not invoked on error results (onnx_engine.cpp:380-388)
-        GameState st;
-        st.frame_id = p.frame_id;                                // onnx_engine.cpp:520-521
-        st.timestamp = p.timestamp;
-        const int cnt = std::min<int>(n, max_dets_);
-        st.detections.resize((size_t)cnt);
-        static_assert(sizeof(zly_det) == sizeof(Detection), "zly_det must be layout-identical to Detection");
-        if (cnt) std::memcpy(st.detections.data(), dets.data(), (size_t)cnt * sizeof(Detection));
-        inference_count_++;
-        {
-            std::lock_guard<std::mutex> lk(stats_mutex_);
-            const double lat = (double)(wallMs() - p.enqueue_ms);
-            latency_window_ms_.push_back(lat);
-            if (latency_window_ms_.size() > 100) latency_window_ms_.pop_front();
-            total_latency_ms_ += lat;
+        for (Done& r : ready) {
+            if (!r.ok) continue;                                 // not invoked on error results (onnx_engine.cpp:380-388)
+            inference_count_++;
+            {
+                std::lock_guard<std::mutex> lk(stats_mutex_);
+                const double lat = (double)(wallMs() - r.enqueue_ms);
+                latency_window_ms_.push_back(lat);
+                if (latency_window_ms_.size() > 100) latency_window_ms_.pop_front();
+                total_latency_ms_ += lat;
+            }
+            if (cb) cb(r.client_id, r.state);
         }
-        p.engine.reset();                                        // an engine replaced by a reload goes with its last request
-        if (cb) cb(p.client_id, st);
     }
 }
 

@@ -61,6 +61,7 @@ public:
 private:
     struct EngineHandle;                                   // owns a zly_engine*; destroyed with its last pending request
     struct Pending {
+        uint64_t seq = 0;
         std::shared_ptr<EngineHandle> engine;
         uint64_t ticket = 0;
         bool failed = false;                               // refused by zly_submit (wrong byte count): no callback, keeps the sequence dense
@@ -84,11 +85,17 @@ private:
     std::string model_hash_;                               // guarded by stats_mutex_
     std::atomic<bool> running_{false};
 
-    mutable std::mutex queue_mutex_;                       // pending_, next_seq_, next_done_, callback_
+    struct Done { uint32_t client_id = 0; bool ok = false; GameState state; uint64_t enqueue_ms = 0; };
+
+    mutable std::mutex queue_mutex_;                       // pending_, finished_, next_emit_, callback_
     std::condition_variable queue_cv_;
-    std::map<uint64_t, Pending> pending_;                  // submitted, not yet handed to the callback; keyed by submission sequence
+    // Requests whose pixels are in the engine's ring, in the order zly_submit returned: the completion thread consumes them in
+    // THIS order (never in sequence order: the owner of the next sequence number may be blocked in zly_submit by ring
+    // back-pressure that only consuming later tickets releases), and re-orders the results by sequence number for the callback.
+    std::deque<Pending> pending_;
+    std::map<uint64_t, Done> finished_;
     std::atomic<uint64_t> next_seq_{0};
-    uint64_t next_done_ = 0;
+    uint64_t next_emit_ = 0;
     InferenceCallback callback_;
 
     std::atomic<uint64_t> inference_count_{0}, inference_errors_{0}, dropped_frames_{0};
