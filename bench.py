@@ -36,6 +36,37 @@ import zly_model as zm  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0         # HBM3E spec peak
+ATTAINABLE_HBM_GBS = 6290.0   # the bandwidth the per-layer attainable time is priced against
+
+
+def per_launch_roofline(ops, kernels, ms, nb):
+    """per launch  attainable_us = max(flops / peak_mfma, bytes / 6.29 TB/s)  next to the achieved time, and their sum.
+    flops / bytes are ALGORITHMIC per op (2 * MAC; input read once + output written once + weights, un-fused) times the frames
+    of the launch; ops that a fused kernel covers (second conv of a bottleneck pair, preprocess inside the stem) are merged
+    into the launch that runs them.  frac = attainable / achieved (1.0 = on its roofline; a fused launch can exceed 1 against
+    the un-fused byte count)."""
+    rows = []
+    carry_gf = carry_mb = 0.0
+    for o, k, m in zip(ops, kernels, ms):
+        gf, mb = o["flops"] * nb / 1e9, o["bytes"] * nb / 1e6
+        if m <= 0:
+            if o["kind"] == 1 and rows:            # second conv of a fused bottleneck pair: ran inside the previous launch
+                rows[-1]["gflop"] += gf; rows[-1]["MB"] += mb
+                rows[-1]["op"] += "+" + o["name"].split(".")[-1]
+            else:                                  # preprocess inside the stem kernel / Detect levels covered by the last tail launch
+                carry_gf += gf; carry_mb += mb
+            continue
+        rows.append({"op": o["name"], "kernel": k, "kind": o["kind"], "us": float(m) * 1e3, "gflop": gf + carry_gf, "MB": mb + carry_mb})
+        carry_gf = carry_mb = 0.0
+    out = []
+    for r in rows:
+        t_mfma = r["gflop"] * 1e9 / (PEAK_BF16_TFLOPS * 1e12) * 1e6
+        t_hbm = r["MB"] * 1e6 / (ATTAINABLE_HBM_GBS * 1e9) * 1e6
+        att = max(t_mfma, t_hbm)
+        out.append({"op": r["op"], "kernel": r["kernel"], "us": round(r["us"], 2), "gflop": round(r["gflop"], 3), "MB": round(r["MB"], 2),
+                    "attainable_us": round(att, 2), "bound": "mfma" if t_mfma >= t_hbm else "hbm", "frac": round(att / r["us"], 4),
+                    "TFLOPs": round(r["gflop"] / r["us"] * 1e-3 * 1e3, 1), "GBps": round(r["MB"] / r["us"] * 1e3, 0), "is_conv": r["kind"] == 1})
+    return out
 
 
 def log(msg):
@@ -293,6 +324,9 @@ def run():
                 ms8 = eng.profile_ops(frames.data_ptr(), nb, 416, 416, reps=10)
                 os.environ["ZLY_PROFILE_INNER"] = "1"
                 ms = eng.profile_ops(frames.data_ptr(), nb, 416, 416, reps=20)
+                launches = per_launch_roofline(ops, eng.op_kernels(nb), ms, nb)
+                conv_l = [r for r in launches if r["is_conv"]]
+                dom = max(conv_l, key=lambda r: r["us"])
                 conv = [(o, m) for o, m in zip(ops, ms) if o["kind"] == 1 and m > 0]   # m == 0: fused into the previous launch (bottleneck pairs); its flops still count below
                 conv8_ms = float(sum(m for o, m in zip(ops, ms8) if o["kind"] == 1))
                 conv_ms = float(sum(m for _, m in conv))
@@ -313,7 +347,19 @@ def run():
                             "slowest_convs_ms": {o["name"]: round(float(m), 4) for o, m in top},
                             "back_to_back": {"kernel_ms_per_step": round(conv8_ms, 4), "achieved": round(flops / (conv8_ms * 1e-3) / 1e12, 3),
                                              "frac": round(flops / (conv8_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 5)},
-                            "method": "zly_profile_ops: 20 eager passes on the engine's stream, one hipEvent pair per launch (back_to_back: 8 launches per pair, / 8)"}
+                            "method": "zly_profile_ops: 20 eager passes on the engine's stream, one hipEvent pair per launch (back_to_back: 8 launches per pair, / 8)",
+                            # per-layer attainable time next to achieved
+                            "attainable_ms_per_step": round(sum(r["attainable_us"] for r in launches) / 1e3, 4),
+                            "attainable_conv_ms_per_step": round(sum(r["attainable_us"] for r in conv_l) / 1e3, 4),
+                            "achieved_over_attainable": round(float(ms.sum()) / max(1e-9, sum(r["attainable_us"] for r in launches) / 1e3), 2),
+                            "dominant_kernel": {"op": dom["op"], "kernel": dom["kernel"], "us": dom["us"], "bound": dom["bound"],
+                                                "achieved": dom["TFLOPs"] if dom["bound"] == "mfma" else dom["GBps"],
+                                                "unit": "TFLOP/s" if dom["bound"] == "mfma" else "GB/s",
+                                                "peak": PEAK_BF16_TFLOPS if dom["bound"] == "mfma" else PEAK_HBM_GBS,
+                                                "frac_of_peak": round((dom["TFLOPs"] / PEAK_BF16_TFLOPS) if dom["bound"] == "mfma" else (dom["GBps"] / PEAK_HBM_GBS), 4),
+                                                "attainable_us": dom["attainable_us"], "frac_of_attainable": dom["frac"],
+                                                "mfma_frac": round(dom["TFLOPs"] / PEAK_BF16_TFLOPS, 4)},
+                            "per_launch": [{k: v for k, v in r.items() if k != "is_conv"} for r in launches] if nb == B else None}
                 if a.dump_ops:
                     with open(a.dump_ops, "a") as f:
                         f.write(f"# batch {nb}: per-op mean ms over 20 eager reps (hipEvents around every launch)\n")

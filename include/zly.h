@@ -203,6 +203,8 @@ int32_t zly_num_classes(const zly_engine* e);
 int32_t zly_num_anchors(const zly_engine* e);
 int32_t zly_num_ops(const zly_engine* e);
 int32_t zly_op_info_at(const zly_engine* e, int32_t i, zly_op_info* out);
+/* name and tile shape of the kernel op i launches at batch size n (the engine picks kernels per launch size) */
+int32_t zly_op_kernel_name(zly_engine* e, int32_t i, int32_t n, char* out, size_t cap);
 /* Runs the device path `reps` times on n resident frames with a hipEvent pair around every
  * kernel launch (no graph) and writes the mean milliseconds per op to ms_out[zly_num_ops]. */
 int32_t zly_profile_ops(zly_engine* e, int32_t n, const void* d_frames, int32_t w, int32_t h,

@@ -216,28 +216,52 @@ def test_forward_bf16_vs_emulating_oracle(eng16, weights_path, oracle, ref_bf16)
     e.close()
 
 
+@pytest.fixture(scope="module")
+def eng16d(weights_path):
+    """production kernels + the debug dumps (model.0 from inside the fused stem kernel, the Detect tail's logits)"""
+    e = zly.Engine(weights_path, dtype=zly.DTYPE_BF16, max_batch=8, max_dets=512, warmup_runs=1, flags=zly.FLAG_DUMP_LOGITS)
+    yield e
+    e.close()
+
+
+def _assert_stem_close(g, t):
+    assert g.shape == t.shape
+    assert np.all(np.abs(g - t) <= 2.0 ** -7 * np.abs(t) + 1e-6), float(np.abs(g - t).max())      # same inputs: at most 1 bf16 ulp apart
+    assert np.mean(g != t) < 0.02                                                                   # and flips are rare, not systematic
+
+
 @pytest.mark.parametrize("w,h", [(800, 600), (1920, 1080), (417, 415), (64, 48), (1, 1), (416, 416)])
-def test_fused_stem_kernel_vs_oracle(eng16, oracle, ref_bf16, w, h):
-    """stem_fused_kernel -- the PRODUCTION preprocess + model.0 of the bf16 engine (kernels_stem.hip) -- has its own
-    nearest-neighbour resize map, BGR->RGB and u8 -> bf16 scaling.  After detect() on a frame of another size, the
-    model.0 tensor it left in HBM must equal conv(preProcess(frame)) of the oracles (reference onnx_engine.cpp:673-693
-    for the map) to 1 bf16 ulp: a resize index off by one moves whole pixels by O(1)."""
+@pytest.mark.parametrize("stem1", [True, False])
+def test_fused_stem_kernels_vs_oracle(eng16d, weights_path, oracle, ref_bf16, monkeypatch, w, h, stem1):
+    """The PRODUCTION front of the bf16 engine has its own nearest-neighbour resize map, BGR->RGB and u8 -> bf16 scaling:
+    stem_model1_kernel (preprocess + model.0 + model.1, the stem map stays in LDS; kernels_stem.hip) and, when that fusion is
+    off (ZLY_NO_STEM1 / other widths), stem_fused_kernel (preprocess + model.0).  After detect() on a frame of another size,
+    the model.0 tensor must equal conv(preProcess(frame)) of the oracles (reference onnx_engine.cpp:673-693 for the map)
+    to 1 bf16 ulp -- a resize index off by one moves whole pixels by O(1) -- and model.1, computed from the LDS map, must
+    match the oracle's at layer tolerance."""
     rng = np.random.default_rng(w * 10007 + h)
     img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
     rc, pre = oracle.preprocess(img, 416, 416)
     assert rc == 0
     ref_bf16.forward(torch.from_numpy(pre[None]))
-    t = ref_bf16.taps["model.0"][0].numpy()
-    eng16.detect(img, cap=8)
-    g = eng16.tap("model.0", 0)
-    assert g.shape == t.shape
-    assert np.all(np.abs(g - t) <= 2.0 ** -7 * np.abs(t) + 1e-6), float(np.abs(g - t).max())
-    assert np.mean(g != t) < 0.02
+    t0, t1 = ref_bf16.taps["model.0"][0].numpy(), ref_bf16.taps["model.1"][0].numpy()
+    if stem1:
+        e = eng16d
+        assert "stem_model1_kernel" in e.op_kernels(1)[1]
+    else:
+        monkeypatch.setenv("ZLY_NO_STEM1", "1")
+        e = zly.Engine(weights_path, max_batch=2, max_dets=64, warmup_runs=0)
+        assert "stem_fused_kernel" in e.op_kernels(1)[1]
+    e.detect(img, cap=8)
+    _assert_stem_close(e.tap("model.0", 0), t0)
+    _assert_layer_close(e.tap("model.1", 0), t1, "model.1")
     # and inside a mixed-size batch (per-frame descriptors), as the last frame
     other = zm.synth_frames(1, 416, 416, seed=2, rects=False)[0]
-    eng16.detect_batch([other, img], cap=8)
-    g = eng16.tap("model.0", 1)
-    assert np.all(np.abs(g - t) <= 2.0 ** -7 * np.abs(t) + 1e-6) and np.mean(g != t) < 0.02
+    e.detect_batch([other, img], cap=8)
+    _assert_stem_close(e.tap("model.0", 1), t0)
+    _assert_layer_close(e.tap("model.1", 1), t1, "model.1")
+    if not stem1:
+        e.close()
 
 
 @pytest.mark.parametrize("n", [16, 64])
@@ -290,6 +314,13 @@ def test_throughput_kernels_on_ragged_maps(weights_path, oracle, monkeypatch, w,
     checked = _check_taps(e, ref, range(n), skip_ok=(".m.0.cv1", ".m.1.cv1"))
     assert len(checked) >= 59, checked
     _assert_bf16_close(got, want)
+    # the detect path's front (stem_model1_kernel: ragged tiles of the model.1 map, stem halo beyond the map edges)
+    res = e.detect_batch(list(frames), cap=64)
+    for i in range(n):
+        _assert_stem_close(e.tap("model.0", i), ref.taps["model.0"][i].numpy())
+        for name in ("model.1", "model.2.cv2", "model.9.cv2"):
+            _assert_layer_close(e.tap(name, i), ref.taps[name][i].numpy(), f"{name}[{i}] after detect")
+    assert len(res) == n
     e.close()
 
 

@@ -132,6 +132,9 @@ struct zly_engine {
 
     bool stem_fused = false;          // bf16 + 16-channel stem: preprocess and model.0 are one kernel on the detect paths
     StemArgs stem{};
+    bool stem1 = false;               // ... and model.1 (32 channels) as well: the stem map stays in LDS (kernels_stem.hip: stem_model1_kernel)
+    Stem1Args stem1a{};
+    bool last_stem1 = false;          // the most recent call ran it (model.0 then only exists in HBM with ZLY_FLAG_DUMP_LOGITS)
     hipStream_t stream = nullptr;
     hipStream_t side[2] = {nullptr, nullptr};     // P3 / P4 Detect branches (forked from and joined to the main stream)
     hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join[2] = {nullptr, nullptr};
@@ -332,6 +335,18 @@ static int build_plan(zly_engine* e, std::string* err)
     e->stem_fused = e->dtype == ZLY_DTYPE_BF16 && ch[0] == 16;
     if (e->stem_fused) ok = ok && pb.pack_only("model.0", 4, &stem_w, &stem_b, &stem_nk) && stem_nk == 2;
     ok = ok && pb.conv({"model.1"}, View{a0, 0, ch[0]}, View{a1, 0, ch[1]});
+    size_t m1_w = 0, m1_b = 0;
+    e->stem1 = e->stem_fused && ch[1] == 32 && !(e->cfg.flags & ZLY_FLAG_NO_FUSION) && getenv("ZLY_NO_STEM1") == nullptr && ok;
+    if (e->stem1) {
+        // model.1 in the fused kernel's tiling: one 16x16x16 MFMA per tap (k = ci), pair-permuted rows, bias in channel order
+        const ConvRec* r = m.find("model.1");
+        std::vector<uint8_t> w;
+        std::vector<float> b;
+        int cout = 0, cout_pad = 0, nk = 0;
+        repack_conv({r}, ch[0], 16, true, &w, &b, &cout, &cout_pad, &nk, true, 4);
+        if (nk != 9 || cout_pad != 32 || r->k != 3 || r->stride != 2) e->stem1 = false;
+        else { m1_w = pb.append(w.data(), w.size()); m1_b = pb.append(b.data(), b.size() * sizeof(float)); }
+    }
     ok = ok && pb.c2f("model.2", View{a1, 0, ch[1]}, View{a2, 0, ch[1]}, nb[0], true, H4, W4);
     ok = ok && pb.conv({"model.3"}, View{a2, 0, ch[1]}, View{a3, 0, ch[2]});
     ok = ok && pb.c2f("model.4", View{a3, 0, ch[2]}, View{cat14, ch[3], ch[2]}, nb[1], true, H8, W8);          // P3 -> cat14
@@ -457,6 +472,16 @@ static int build_plan(zly_engine* e, std::string* err)
         st.out = e->bufs[(size_t)a0].ptr; st.out_cs = ch[0]; st.out_co = 0;
         st.tw = W; st.th = H; st.Ho = H2; st.Wo = W2; st.Cout = ch[0]; st.tiles_x = stem_tiles_x(W2);
     }
+    if (e->stem1) {
+        Stem1Args& s1 = e->stem1a;
+        s1.st = e->stem;
+        s1.w1 = (const char*)e->d_weights + m1_w; s1.b1 = (const float*)((const char*)e->d_weights + m1_b);
+        s1.out1 = e->bufs[(size_t)a1].ptr; s1.out1_cs = ch[1]; s1.out1_co = 0;
+        s1.H1 = H4; s1.W1 = W4;
+        stem1_plan(H4, W4, &s1.TH, &s1.TW);
+        s1.tiles_x = (W4 + s1.TW - 1) / s1.TW; s1.tiles_y = (H4 + s1.TH - 1) / s1.TH;
+        s1.dump = (e->cfg.flags & ZLY_FLAG_DUMP_LOGITS) ? 1 : 0;
+    }
     for (Op& op : e->ops) {
         if (op.kind != OP_HEAD) continue;
         for (int l = 0; l < 3; ++l) {
@@ -505,6 +530,7 @@ static const PairPlan* pair_active(zly_engine* e, const Op& op, int n)
 // ops that launch nothing at this batch size (second conv of a fused pair; per-level tail ops when one launch covers all)
 static bool op_is_noop(zly_engine* e, const Op& op, int n)
 {
+    if (op.kind == OP_CONV && e->stem1 && op.name == "model.1") return true;     // detect paths: computed by stem_model1_kernel (booked on model.0)
     if (op.kind == OP_CONV && op.pair == 2) return pair_active(e, op, n) != nullptr;
     if (op.kind == OP_HEAD && op.level != 2) return !lanes_active(n) || getenv("ZLY_NO_TAIL_SPLIT") != nullptr;
     return false;
@@ -670,7 +696,13 @@ static int run_path(zly_engine* e, int n, const uint8_t* d_src, void* d_slabs_ou
     const bool fused = with_pre && e->stem_fused;
     size_t first = 1;
     if (sample) HIP_TRY(hipEventRecord(e->ev_t[0], s), ZLY_ERR_INFERENCE);
-    if (fused) {
+    e->last_stem1 = fused && e->stem1;
+    if (fused && e->stem1) {
+        Stem1Args st = e->stem1a;
+        st.st.src = d_src; st.st.desc = e->d_desc;
+        HIP_TRY(launch_stem_model1(st, n, s), ZLY_ERR_INFERENCE);
+        first = 3;
+    } else if (fused) {
         StemArgs st = e->stem;
         st.src = d_src; st.desc = e->d_desc;
         HIP_TRY(launch_stem_fused(st, n, s), ZLY_ERR_INFERENCE);
@@ -1172,6 +1204,7 @@ int32_t zly_create(const zly_config* cfg, zly_engine** out)
     HIP_TRY(hipSetDevice(cfg->device), ZLY_ERR_SYSTEM);
     HIP_TRY(conv_init(), ZLY_ERR_SYSTEM);
     HIP_TRY(pair_init(), ZLY_ERR_SYSTEM);
+    HIP_TRY(stem1_init(), ZLY_ERR_SYSTEM);
 
     zly_engine* e = new zly_engine();
     e->cfg = *cfg;
@@ -1504,6 +1537,8 @@ int32_t zly_debug_tap(zly_engine* e, const char* name, int32_t idx, float* out, 
         auto jt = e->tap_final.find(name);
         if (it != e->tap_index.end()) {
             const Op& op = e->ops[(size_t)it->second.first];
+            if (e->last_stem1 && op.name == "model.0" && !(e->cfg.flags & ZLY_FLAG_DUMP_LOGITS))
+                return fail(ZLY_ERR_INVALID_ARGUMENT, "tap model.0 stays in LDS inside the fused stem kernel; create the engine with ZLY_FLAG_DUMP_LOGITS (or ZLY_FLAG_NO_FUSION)");
             if (op.pair == 1 && e->last_n > 0 && pair_active(e, op, e->last_n))
                 return fail(ZLY_ERR_INVALID_ARGUMENT, std::string("tap ") + name + " stays in LDS inside the fused bottleneck kernel at this batch size; create the engine with ZLY_FLAG_NO_FUSION");
             buf = op.out.buf; co = op.out.co + op.tap_co[(size_t)it->second.second]; C = op.tap_c[(size_t)it->second.second];
@@ -1546,6 +1581,39 @@ int32_t zly_op_info_at(const zly_engine* e, int32_t i, zly_op_info* out)
     return ZLY_OK;
 }
 
+int32_t zly_op_kernel_name(zly_engine* e, int32_t i, int32_t n, char* out, size_t cap)
+{
+    if (!e || !out || cap < 8 || i < 0 || i >= (int32_t)e->ops.size() || n < 1 || n > e->cfg.max_batch) return fail(ZLY_ERR_INVALID_ARGUMENT, "bad argument");
+    std::lock_guard<std::mutex> lk(e->mu);
+    const Op& op = e->ops[(size_t)i];
+    std::string k;
+    switch (op.kind) {
+    case OP_PREPROCESS: k = e->stem_fused ? "(fused into stem_fused_kernel)" : "preprocess_kernel"; break;
+    case OP_SPPF: k = "sppf_pool_kernel"; break;
+    case OP_HEAD: k = op_is_noop(e, op, n) ? "(covered by the last tail launch)" : "head_fused_kernel"; break;
+    case OP_NMS: k = "nms_kernel"; break;
+    case OP_CONV: {
+        if (i == 1 && e->stem1) { k = "stem_model1_kernel (preprocess+model.0+model.1)"; break; }
+        if (i == 2 && e->stem1) { k = "(fused into the previous launch)"; break; }
+        if (i == 1 && e->stem_fused) { k = "stem_fused_kernel"; break; }
+        if (op.pair && pair_active(e, op, n)) { k = op.pair == 1 ? "bottleneck_pair_kernel<" + std::to_string(op.pair_c) + ">" : "(fused into the previous launch)"; break; }
+        const Buffer& ob = e->bufs[(size_t)op.out.buf];
+        const int cin = op.in.C + (op.in2.buf >= 0 ? op.in2.C : 0);
+        ConvLaunch c;
+        conv_pick_config(e->dtype, op.ks, op.stride, cin, op.cout_pad, n, ob.H, ob.W, &c,
+                         op.in2.buf < 0 && op.res.buf < 0 && op.act && !op.out_f32 && op.cout % 32 == 0);
+        if (c.lds) k = "conv3x3_lds_kernel<S=" + std::to_string(op.stride) + ",CT=" + std::to_string(c.ct) + ",PT=" + std::to_string(c.pt) + (c.wres ? ",wres>" : ">");
+        else if (c.stream) k = "conv1x1_stream_kernel<CT=" + std::to_string(c.ct) + ",PT=" + std::to_string(c.pt) + ",NK=" + std::to_string((cin + 31) / 32) + ">";
+        else k = std::string("conv_igemm_kernel<") + (op.ks == 1 ? (op.in2.buf >= 0 ? "1x1 dual-source" : "1x1") : (c.fastk ? "3x3" : "3x3 generic-K")) +
+                 ",CT=" + std::to_string(c.ct) + ",PT=" + std::to_string(c.pt) + ",KSPLIT=" + std::to_string(c.ksplit) + ">";
+        break;
+    }
+    default: k = "?";
+    }
+    snprintf(out, cap, "%s", k.c_str());
+    return ZLY_OK;
+}
+
 int32_t zly_profile_ops(zly_engine* e, int32_t n, const void* d_frames, int32_t w, int32_t h, int32_t reps, float* ms_out)
 {
     if (!e) return fail(ZLY_ERR_NOT_INITIALIZED, "Engine not running");
@@ -1576,6 +1644,12 @@ int32_t zly_profile_ops(zly_engine* e, int32_t n, const void* d_frames, int32_t 
             for (int k = 0; k < reps_i && hr == hipSuccess; ++k) {
                 if (e->stem_fused && i == 0) {
                     // shipped path: preprocess is part of the stem kernel; its time is booked on ops[1] (model.0)
+                } else if (e->stem1 && i == 1) {
+                    Stem1Args st = e->stem1a;
+                    st.st.src = (const uint8_t*)d_frames; st.st.desc = e->d_desc;
+                    hr = launch_stem_model1(st, n, e->stream);
+                } else if (e->stem1 && i == 2) {
+                    // model.1 ran inside the stem kernel
                 } else if (e->stem_fused && i == 1) {
                     StemArgs st = e->stem;
                     st.src = (const uint8_t*)d_frames; st.desc = e->d_desc;
@@ -1607,7 +1681,7 @@ int32_t zly_profile_ops(zly_engine* e, int32_t n, const void* d_frames, int32_t 
             else st.total_forward_ms += acc[i];
         });
     }
-    e->last_n = n;
+    e->last_n = n; e->last_stem1 = e->stem1;
     return ZLY_OK;
 }
 

@@ -79,6 +79,18 @@ struct StemArgs {
 };
 hipError_t launch_stem_fused(const StemArgs& a, int n, hipStream_t s);
 int stem_tiles_x(int Wo);
+// preprocess + model.0 + model.1 in one kernel (the stem map stays in LDS); st.out is only written with dump = 1 (debug taps)
+struct Stem1Args {
+    StemArgs st;
+    const void* w1; const float* b1;          // model.1 weights tiled [2][9 taps][lane][4] (k = ci per tap, pair-permuted rows), bias in channel order
+    void* out1; int out1_cs, out1_co;
+    int H1, W1;                               // model.1 output map
+    int TH, TW, tiles_x, tiles_y;
+    int dump;
+};
+void       stem1_plan(int H1, int W1, int* th, int* tw);
+hipError_t stem1_init();
+hipError_t launch_stem_model1(const Stem1Args& a, int n, hipStream_t s);
 
 // kernels_head.hip -- fused Detect head (final 1x1 convs + DFL + dist2bbox + sigmoid + decode/threshold)
 struct HeadLevel {

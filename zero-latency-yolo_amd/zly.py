@@ -36,7 +36,7 @@ SYMBOLS = [
     "zly_default_config", "zly_create", "zly_destroy", "zly_last_error", "zly_version",
     "zly_detect", "zly_detect_batch", "zly_submit", "zly_poll", "zly_wait", "zly_detect_device", "zly_slab_bytes", "zly_read_slabs", "zly_sync", "zly_join",
     "zly_preprocess", "zly_forward", "zly_head_tensor", "zly_postprocess", "zly_debug_tap",
-    "zly_num_classes", "zly_num_anchors", "zly_num_ops", "zly_op_info_at", "zly_profile_ops", "zly_get_stats",
+    "zly_num_classes", "zly_num_anchors", "zly_num_ops", "zly_op_info_at", "zly_op_kernel_name", "zly_profile_ops", "zly_get_stats",
 ]
 
 DET_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("w", "<f4"), ("h", "<f4"), ("confidence", "<f4"),
@@ -110,6 +110,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.zly_num_anchors.argtypes = [vp]; lib.zly_num_anchors.restype = i32
     lib.zly_num_ops.argtypes = [vp]; lib.zly_num_ops.restype = i32
     lib.zly_op_info_at.argtypes = [vp, i32, C.POINTER(OpInfo)]; lib.zly_op_info_at.restype = i32
+    lib.zly_op_kernel_name.argtypes = [vp, i32, i32, C.c_char_p, sz]; lib.zly_op_kernel_name.restype = i32
     lib.zly_profile_ops.argtypes = [vp, i32, vp, i32, i32, i32, vp]; lib.zly_profile_ops.restype = i32
     lib.zly_get_stats.argtypes = [vp, C.POINTER(Stats)]; lib.zly_get_stats.restype = i32
     if path is None:
@@ -269,6 +270,15 @@ class Engine:
             info = OpInfo()
             _check(self.lib, self.lib.zly_op_info_at(self.h, i, C.byref(info)))
             out.append(dict(name=info.name.decode(), kind=info.kind, flops=info.flops_per_frame, bytes=info.bytes_per_frame))
+        return out
+
+    def op_kernels(self, n: int) -> List[str]:
+        """kernel (and tile shape) every op launches at batch size n"""
+        out = []
+        buf = C.create_string_buffer(96)
+        for i in range(self.lib.zly_num_ops(self.h)):
+            _check(self.lib, self.lib.zly_op_kernel_name(self.h, i, n, buf, 96))
+            out.append(buf.value.decode())
         return out
 
     def profile_ops(self, d_frames_ptr: int, n: int, w: int, h: int, reps: int = 5) -> np.ndarray:
