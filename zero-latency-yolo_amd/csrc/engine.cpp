@@ -149,6 +149,8 @@ struct zly_engine {
     int t_frames = 0;
     unsigned sample_ctr = 0;
 
+    int cu_part_n = 1;                // ZLY_CU_PART: number of CU partitions (1 = whole chip)
+    uint32_t cu_mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     std::atomic<Ingest*> ingest{nullptr};   // created by the first zly_submit (under mu), read lock-free afterwards
 
     std::mutex mu;                    // serialises every call that touches engine / device state
@@ -503,7 +505,7 @@ static int build_plan(zly_engine* e, std::string* err)
 // than the overlap buys (0.27 -> 0.34 ms/frame); from batch 16 up the branches are long enough to pay
 static bool lanes_active(int n)
 {
-    static const bool no_lanes = getenv("ZLY_NO_LANES") != nullptr;     // tuning aid
+    static const bool no_lanes = getenv("ZLY_NO_LANES") != nullptr || getenv("ZLY_CU_PART") != nullptr;     // tuning aid; a CU partition runs one chain
     return n >= 16 && !no_lanes;
 }
 
@@ -1217,9 +1219,25 @@ int32_t zly_create(const zly_config* cfg, zly_engine** out)
     int rc = load_zlyw(e->weights_path.c_str(), &e->model, &err);
     if (rc != ZLY_OK) { destroy_engine(e); return fail(rc, err); }
     e->nc = e->model.nc;
-    bool sok = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) == hipSuccess;
+    // ZLY_CU_PART="i/n": this engine's streams only use the i-th of n equal slices of the chip's compute units (spatial
+    // partitioning: several engines run side by side, the launch-latency-bound small-map layers of one beside the
+    // bandwidth-bound layers of another).  Experiment switch: see DESIGN.md section 5.
+    if (const char* cp = getenv("ZLY_CU_PART")) {
+        int pi = 0, pn = 1;
+        if (sscanf(cp, "%d/%d", &pi, &pn) == 2 && pn >= 1 && pn <= 8 && pi >= 0 && pi < pn) {
+            e->cu_part_n = pn;
+            const int per = 256 / pn;
+            for (int b = pi * per; b < (pi + 1) * per; ++b) e->cu_mask[b / 32] |= 1u << (b % 32);
+            set_num_cus(per);
+        }
+    }
+    auto make_stream = [&](hipStream_t* st) {
+        if (e->cu_part_n > 1) return hipExtStreamCreateWithCUMask(st, 8, e->cu_mask) == hipSuccess;
+        return hipStreamCreateWithFlags(st, hipStreamNonBlocking) == hipSuccess;
+    };
+    bool sok = make_stream(&e->stream);
     for (int i = 0; i < 2 && sok; ++i) {
-        sok = hipStreamCreateWithFlags(&e->side[i], hipStreamNonBlocking) == hipSuccess &&
+        sok = make_stream(&e->side[i]) &&
               hipEventCreateWithFlags(&e->ev_fork[i], hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming) == hipSuccess;
     }
@@ -1245,7 +1263,7 @@ int32_t zly_create(const zly_config* cfg, zly_engine** out)
     e->cur_cand = e->d_cand; e->cur_count = e->d_count;
     if (cfg->flags & ZLY_FLAG_ASYNC_NMS) {
         bool aok = hipMalloc((void**)&e->d_cand_alt, B * N * sizeof(Cand)) == hipSuccess && hipMalloc((void**)&e->d_count_alt, B * sizeof(int)) == hipSuccess &&
-                   hipStreamCreateWithFlags(&e->nms_stream, hipStreamNonBlocking) == hipSuccess &&
+                   make_stream(&e->nms_stream) &&
                    hipEventCreateWithFlags(&e->ev_head, hipEventDisableTiming) == hipSuccess &&
                    hipEventCreateWithFlags(&e->ev_nms[0], hipEventDisableTiming) == hipSuccess &&
                    hipEventCreateWithFlags(&e->ev_nms[1], hipEventDisableTiming) == hipSuccess;

@@ -799,6 +799,10 @@ static size_t lds_bytes(int stride, int pt, int ct, int wchunks = 1) {
     return patch + (size_t)wchunks * 9 * ct * 1024;
 }
 
+static int g_num_cus = 256;
+int num_cus() { return g_num_cus; }
+void set_num_cus(int n) { g_num_cus = n < 1 ? 1 : (n > 256 ? 256 : n); }
+
 // dynamic LDS above 64 KiB needs an opt-in per kernel; done once, outside any stream capture
 hipError_t conv_init()
 {
@@ -969,7 +973,7 @@ hipError_t launch_conv(int dtype, const ConvArgs& a, const ConvLaunch& cfg, hipS
             occ = o > 4 ? 4 : o;
         }
         const char* wv = getenv("ZLY_LDS_WGS_PER_CU");       // tuning aid: force
-        const int max_wgs = (wv ? atoi(wv) : occ) * 256;
+        const int max_wgs = (wv ? atoi(wv) : occ) * num_cus();
         if (gx * ytiles > max_wgs) gx = max_wgs / ytiles;  // never more than are resident: a persistent workgroup
         if (gx > total) gx = total;                        // that has to wait for a slot runs a whole round alone
         hipLaunchKernelGGL(fn, dim3(gx, ytiles, 1), dim3(256), lds_bytes(a.stride, cfg.pt, cfg.ct, cfg.wres ? nchunks : 1), s, a, tiles_x, tiles_per_img, total, cfg.wres);
@@ -986,7 +990,8 @@ hipError_t launch_conv(int dtype, const ConvArgs& a, const ConvLaunch& cfg, hipS
         const int ngroups = (a.M + 16 * cfg.pt - 1) / (16 * cfg.pt);
         int gx = (ngroups + 3) / 4;
         const char* sw = getenv("ZLY_STREAM_WGS");         // tuning / tests: total persistent workgroups (default ~4 per CU)
-        const int cap = (sw && atoi(sw) > 0 ? atoi(sw) : 1024) / ytiles > 0 ? (sw && atoi(sw) > 0 ? atoi(sw) : 1024) / ytiles : 1;
+        const int wgs = sw && atoi(sw) > 0 ? atoi(sw) : 4 * num_cus();
+        const int cap = wgs / ytiles > 0 ? wgs / ytiles : 1;
         if (gx > cap) gx = cap;
         hipLaunchKernelGGL(sf, dim3(gx, ytiles, 1), dim3(256), 0, s, a, ngroups);
         return hipGetLastError();

@@ -275,7 +275,7 @@ static size_t pair_lds_bytes(int c, int th, int tw)
 bool pair_plan(int c, int n, int H, int W, PairPlan* plan)
 {
     if (c != 16 && c != 32 && c != 64) return false;
-    const int ncu = 256, nw = pair_nw(c);
+    const int ncu = num_cus(), nw = pair_nw(c);
     double best = 1e30;
     for (int th = 4; th <= 32; ++th) {
         for (int tw = 8; tw <= 64; ++tw) {

@@ -41,6 +41,11 @@ struct ConvArgs {
 
 struct ConvLaunch { int ks, ct, pt, fastk, ksplit, lds, stream, wres; };
 
+// compute units the engine's streams may use: 256 (whole chip), or the size of its CU partition (engine.cpp: ZLY_CU_PART).  The
+// persistent grids of the conv kernels are sized from it (a persistent workgroup that waits for a slot runs a whole round alone).
+int  num_cus();
+void set_num_cus(int n);
+
 // kernels_conv.hip
 hipError_t launch_conv(int dtype, const ConvArgs& a, const ConvLaunch& cfg, hipStream_t s);
 void       conv_pick_config(int dtype, int ks, int stride, int cin, int cout_pad, int n, int Ho, int Wo, ConvLaunch* cfg,
