@@ -215,6 +215,14 @@ struct PlanBuilder {
         std::vector<uint8_t> w;
         std::vector<float> b;
         repack_conv(srcs, cin_total, kstep, e->dtype == ZLY_DTYPE_BF16, &w, &b, &op.cout, &op.cout_pad, &op.nk, true);
+        // 5 channel tiles (the 80-channel Detect class branch) suit no kernel's channel blocking: CT = 5 needs more registers than
+        // two waves per SIMD leave.  One whole zero tile is appended instead (6 tiles = 2 blocks of CT = 3); its outputs are never
+        // stored (channel >= Cout) -- 20 % more MFMAs on these layers, but the LDS-tiled kernel instead of the direct one.
+        if (e->dtype == ZLY_DTYPE_BF16 && op.ks == 3 && op.cout_pad == 80 && cin_total % 32 == 0 && getenv("ZLY_NO_COUT_PAD") == nullptr) {
+            w.resize(w.size() + (size_t)op.nk * 1024, 0);
+            b.resize(b.size() + 16, 0.0f);
+            op.cout_pad = 96;
+        }
         if (out.C != op.cout || out.co % 4 != 0 || ob.C % 4 != 0 || out.co + out.C > ob.C) { err = "bad output view for " + names[0]; return false; }
         if (out_f32 != ob.f32) { err = "output dtype mismatch for " + names[0]; return false; }
         const int Ho = ob.H, Wo = ob.W;
@@ -391,13 +399,16 @@ static int build_plan(zly_engine* e, std::string* err)
     int block0 = 0;
     for (int l = 0; l < 3 && ok; ++l) {
         const std::string L = std::to_string(l);
-        const int hd1 = pb.add_buffer("detect." + L + ".stem", fh[l], fw[l], c2 + c3);
+        // the class branch's 80 channels are stored as 96 (16 zero channels, never written) so that its second 3x3 conv has
+        // Cin % 32 == 0 and takes the LDS-tiled kernel; the padded k-steps carry zero weights
+        const int c3s = (e->dtype == ZLY_DTYPE_BF16 && c3 % 32 != 0 && c2 % 32 == 0 && getenv("ZLY_NO_CIN_PAD") == nullptr) ? (c3 + 31) / 32 * 32 : c3;
+        const int hd1 = pb.add_buffer("detect." + L + ".stem", fh[l], fw[l], c2 + c3s);
         const int hb2 = pb.add_buffer("detect." + L + ".box2", fh[l], fw[l], c2);
         const int hc2 = pb.add_buffer("detect." + L + ".cls2", fh[l], fw[l], c3);
         const int hout = pb.add_buffer("detect." + L + ".logits", fh[l], fw[l], 64 + ncp, true);
         ok = ok && pb.conv({"model.22.cv2." + L + ".0", "model.22.cv3." + L + ".0"}, View{feats[l], 0, fch[l]}, View{hd1, 0, c2 + c3});
         ok = ok && pb.conv({"model.22.cv2." + L + ".1"}, View{hd1, 0, c2}, View{hb2, 0, c2});
-        ok = ok && pb.conv({"model.22.cv3." + L + ".1"}, View{hd1, c2, c3}, View{hc2, 0, c3});
+        ok = ok && pb.conv({"model.22.cv3." + L + ".1"}, View{hd1, c2, c3s}, View{hc2, 0, c3});
         HeadLevel& hl = hd.head.lv[l];
         ok = ok && pb.pack_only("model.22.cv2." + L + ".2", c2, &pend[l].wb, &pend[l].bb, &hl.nkb);
         ok = ok && pb.pack_only("model.22.cv3." + L + ".2", c3, &pend[l].wc, &pend[l].bc, &hl.nkc);
@@ -568,7 +579,7 @@ static hipError_t run_op(zly_engine* e, const Op& op, int n, const uint8_t* d_sr
         a.wgt = (const char*)e->d_weights + op.w_off;
         a.bias = (const float*)((const char*)e->d_weights + op.b_off);
         a.out = ob.ptr; a.out_cs = ob.C; a.out_co = op.out.co;
-        a.Ho = ob.H; a.Wo = ob.W; a.Cout = op.cout;
+        a.Ho = ob.H; a.Wo = ob.W; a.Cout = op.cout; a.cout_pad = op.cout_pad;
         if (op.res.buf >= 0) { const Buffer& rb = e->bufs[(size_t)op.res.buf]; a.res = rb.ptr; a.res_cs = rb.C; a.res_co = op.res.co; }
         else { a.res = nullptr; a.res_cs = 0; a.res_co = 0; }
         a.stride = op.stride; a.pad = op.ks / 2;

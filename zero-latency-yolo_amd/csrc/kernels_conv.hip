@@ -953,7 +953,7 @@ hipError_t launch_conv(int dtype, const ConvArgs& a, const ConvLaunch& cfg, hipS
     if (cfg.lds) {
         conv_lds_fn fn = pick_lds(a.stride, cfg.pt, cfg.ct);
         if (!fn || dtype != ZLY_DTYPE_BF16) return hipErrorInvalidValue;
-        const int cout_pad = (a.Cout + 15) / 16 * 16;
+        const int cout_pad = a.cout_pad;
         const int ytiles = cout_pad / (16 * cfg.ct);
         const int th = 4 * cfg.pt;
         const int tiles_x = (a.Wo + 15) / 16, tiles_y = (a.Ho + th - 1) / th;
@@ -985,7 +985,7 @@ hipError_t launch_conv(int dtype, const ConvArgs& a, const ConvLaunch& cfg, hipS
         conv_stream_fn sf = pick_stream(cfg.ct, cfg.pt, nk);
         if (!sf || dtype != ZLY_DTYPE_BF16 || a.in2 || a.res || nk > a.nk || !a.act || a.out_f32 || a.Cout % 32 || a.in_cs % 8 || a.in_co % 8 || a.out_cs % 8 || a.out_co % 8)
             return hipErrorInvalidValue;
-        const int cout_pad = (a.Cout + 15) / 16 * 16;
+        const int cout_pad = a.cout_pad;
         const int ytiles = cout_pad / (16 * cfg.ct);
         const int ngroups = (a.M + 16 * cfg.pt - 1) / (16 * cfg.pt);
         int gx = (ngroups + 3) / 4;
@@ -1007,7 +1007,7 @@ hipError_t launch_conv(int dtype, const ConvArgs& a, const ConvLaunch& cfg, hipS
         fn = pick_mode<float, 2, 1>(mode, cfg.ct);
     }
     if (!fn) return hipErrorInvalidValue;
-    const int cout_pad = (a.Cout + 15) / 16 * 16;
+    const int cout_pad = a.cout_pad;
     const int ytiles = cout_pad / (16 * cfg.ct);
     const int px_per_wg = cfg.ksplit == 4 ? 16 * cfg.pt : 64 * cfg.pt;
     dim3 grid((a.M + px_per_wg - 1) / px_per_wg, ytiles, 1);

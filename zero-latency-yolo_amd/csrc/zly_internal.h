@@ -26,6 +26,7 @@ struct ConvArgs {
     const float* bias;            // [CoutPad]
     void* out;        int out_cs, out_co;
     int Ho, Wo, Cout;
+    int cout_pad;                 // output channels the weight tiles cover (multiple of 16, >= Cout; may include whole zero tiles so that the tile count suits a kernel's channel blocking)
     const void* res;  int res_cs, res_co;    // optional residual (added after the activation)
     int stride, pad;
     int K;                        // ks*ks*Cin
