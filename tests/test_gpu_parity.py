@@ -711,6 +711,7 @@ def test_fused_bottleneck_pairs(weights_path, oracle, monkeypatch, w, h, n):
     bit before the bf16 rounding, so it is compared at its own output and against the oracle."""
     import yolov8_ref
     monkeypatch.setenv("ZLY_PAIR_MIN_TILES", "1")
+    monkeypatch.setenv("ZLY_NO_C2F", "1")                      # this test is about the bottleneck kernel on its own (the C2f kernel contains it)
     frames = zm.synth_frames(n, w, h, seed=31, rects=False)
     x = _pre(oracle, frames, w, h)
     plain = zly.Engine(weights_path, model_w=w, model_h=h, max_batch=n, warmup_runs=0, flags=zly.FLAG_NO_FUSION)
@@ -768,6 +769,57 @@ def test_fused_bottleneck_pairs(weights_path, oracle, monkeypatch, w, h, n):
         assert g.shape == t.shape and np.isfinite(g).all() and _rms(g - t) <= 0.05 * max(_rms(t), 1e-6), name
     _assert_bf16_close(h64, hp)
     e.close(); pl.close()
+
+
+C2F_TAPS = ("model.2.cv1", "model.2.m.0.cv2", "model.2.cv2", "model.4.cv1", "model.4.m.0.cv2", "model.4.m.1.cv2", "model.4.cv2",
+            "model.15.cv1", "model.15.m.0.cv2", "model.15.cv2")
+
+
+@pytest.mark.parametrize("w,h,n", [(416, 416, 16), (320, 256, 2), (352, 288, 5), (416, 416, 1)])
+def test_fused_c2f_blocks(weights_path, oracle, w, h, n):
+    """c2f_kernel (kernels_pair.hip): cv1 -> bottleneck -> cv2 of a C2f block in one launch (model.2, model.15: whole block;
+    model.4: front half + back half), every intermediate in LDS, against the one-kernel-per-conv engine and the rounding-
+    emulating oracle.  The dumps (ZLY_FLAG_DUMP_LOGITS) expose the LDS-resident intermediates.  32-channel blocks accumulate
+    in the order of the unfused kernels: bit-identical taps when the unfused launch does not split K across waves (batch 16);
+    the 16-channel block (model.2) uses one MFMA per tap / per 16-channel concat source, so fp32 sums can differ in the last
+    bit before the bf16 rounding.  Ragged maps (88x72 .. 40x32) put partial tiles on every edge; model.15.cv1 reads its
+    input from two tensors (fused Upsample + Concat)."""
+    import yolov8_ref
+    frames = zm.synth_frames(n, w, h, seed=33, rects=False)
+    x = _pre(oracle, frames, w, h)
+    plain = zly.Engine(weights_path, model_w=w, model_h=h, max_batch=n, warmup_runs=0, flags=zly.FLAG_NO_FUSION)
+    hp = plain.forward(x)
+    tp = {name: [plain.tap(name, i) for i in range(n)] for name in C2F_TAPS}
+    plain.close()
+    e = zly.Engine(weights_path, model_w=w, model_h=h, max_batch=n, warmup_runs=0, flags=zly.FLAG_DUMP_LOGITS)
+    kernels = e.op_kernels(n)
+    assert sum("c2f_kernel" in k for k in kernels) == 4, kernels
+    hf = e.forward(x)
+    with pytest.raises(zly.ZlyError):
+        e.tap("model.2.m.0.cv1", 0)                               # stays in LDS even with the dumps
+    ref = yolov8_ref.load(weights_path, "bf16")
+    ref.forward(torch.from_numpy(x))
+    for name in C2F_TAPS:
+        for i in range(n):
+            g, t = e.tap(name, i), tp[name][i]
+            _assert_layer_close(g, ref.taps[name][i].numpy(), f"{name}[{i}] vs oracle")
+            if n >= 16 and not name.startswith("model.2."):
+                assert np.array_equal(g, t), (name, i, float(np.mean(g != t)))
+            else:
+                assert np.abs(g - t).max() <= 2.0 ** -6 * np.abs(t).max() and np.mean(g != t) < 0.05, (name, i)
+    _assert_bf16_close(hf, hp)
+    e.close()
+    # without the dumps the LDS-resident intermediates cannot be tapped, the block outputs can, and the results are the same
+    e = zly.Engine(weights_path, model_w=w, model_h=h, max_batch=n, warmup_runs=0)
+    h2 = e.forward(x)
+    assert np.array_equal(h2, hf)
+    for name in ("model.2.cv1", "model.15.m.0.cv2", "model.4.m.1.cv2"):
+        with pytest.raises(zly.ZlyError):
+            e.tap(name, 0)
+    for name in ("model.2.cv2", "model.4.cv1", "model.4.m.0.cv2", "model.4.cv2", "model.15.cv2"):
+        assert np.array_equal(e.tap(name, n - 1), e.tap(name, n - 1))
+        _assert_layer_close(e.tap(name, n - 1), ref.taps[name][n - 1].numpy(), name)
+    e.close()
 
 
 def test_four_class_cs16_head(tmp_path, oracle):

@@ -71,6 +71,14 @@ struct Op {
     int pair = 0, pair_c = 0, pair_res = 0;
     View pair_out{-1, 0, 0};
     size_t pair_wA = 0, pair_bA = 0, pair_wB = 0, pair_bB = 0;
+    // fused C2f block (kernels_pair.hip: c2f_kernel): c2f_mode != 0 on the op that launches it (cv1, or the second bottleneck's first
+    // conv for the back half of a two-bottleneck C2f); the ops it covers carry the leader's name and launch nothing when it is active
+    int c2f_mode = 0, c2f_c = 0, c2f_res = 0, c2f_cat = -1, c2f_in_co = 0, c2f_out_co = 0, c2f_nk1 = 0, c2f_nk2 = 0, c2f_cout2 = 0;
+    View c2f_x{-1, 0, 0}, c2f_x2{-1, 0, 0}, c2f_out{-1, 0, 0};
+    size_t c2f_w1 = 0, c2f_b1 = 0, c2f_wA = 0, c2f_bA = 0, c2f_wB = 0, c2f_bB = 0, c2f_w2 = 0, c2f_b2 = 0;
+    std::string c2f_leader_name;       // covered ops (and the leader itself)
+    int c2f_leader = -1;               // index of the leader op (resolved after the ops are ordered)
+    int c2f_vis = 0;                   // this op's output with the fused kernel: 0 = in HBM, 1 = only with ZLY_FLAG_DUMP_LOGITS, 2 = stays in LDS
     HeadArgs head{};                   // OP_HEAD: fused Detect tail
     double flops = 0, bytes = 0;
 };
@@ -139,6 +147,7 @@ struct zly_engine {
     hipStream_t side[2] = {nullptr, nullptr};     // P3 / P4 Detect branches (forked from and joined to the main stream)
     hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join[2] = {nullptr, nullptr};
     std::map<int, hipGraphExec_t> graphs;   // batch size -> captured forward+decode
+    std::map<long, std::pair<bool, C2fPlan>> c2f_plans;     // (c, mode, n, H, W) -> fused C2f tile plan
     std::map<long, std::pair<bool, PairPlan>> pair_plans;   // (c, n, H, W) -> fused bottleneck tile plan (or "run unfused")
     int last_n = 0;
 
@@ -299,7 +308,62 @@ struct PlanBuilder {
             if (!conv({m + ".cv2"}, View{tmp, 0, c}, View{cat, (2 + i) * c, c}, shortcut ? src : View{-1, 0, 0})) return false;
             if (!mark_pair(m, c, shortcut)) return false;
         }
-        return conv({p + ".cv2"}, View{cat, 0, (2 + n) * c}, out);
+        if (!conv({p + ".cv2"}, View{cat, 0, (2 + n) * c}, out)) return false;
+        return mark_c2f(p, cat, c, n, shortcut, in, in2, out);
+    }
+    // The 2 + 2n ops just added are a C2f block: annotate the fused kernel's launch groups (n = 1: the whole block; n = 2: front half
+    // = cv1 + first bottleneck, back half = second bottleneck + cv2).  Weight tilings are shared with the per-conv kernels where the
+    // layout is the same (C = 32); the 16-channel block gets its own cv1 (rows in channel order) and cv2 (k-steps of 16) tilings.
+    bool mark_c2f(const std::string& p, int cat, int c, int n, bool shortcut, View in, View in2, View out) {
+        if (e->dtype != ZLY_DTYPE_BF16 || (c != 16 && c != 32) || (n != 1 && n != 2) || (e->cfg.flags & ZLY_FLAG_NO_FUSION)) return true;
+        const size_t base = e->ops.size() - (size_t)(2 + 2 * n);
+        Op& cv1 = e->ops[base];
+        Op& cv2 = e->ops[e->ops.size() - 1];
+        const int cin = in.C + (in2.buf >= 0 ? in2.C : 0);
+        if (cin % 32 != 0 || (cv2.cout != 32 && cv2.cout != 64) || cv1.cout != 2 * c || !cv1.act || !cv2.act) return true;
+        for (int i = 0; i < n; ++i) if (e->ops[base + 1 + 2 * (size_t)i].pair != 1) return true;       // mark_pair declined
+        size_t w1 = cv1.w_off, b1 = cv1.b_off, w2 = cv2.w_off, b2 = cv2.b_off;
+        int nk1 = cv1.nk, nk2 = cv2.nk;
+        if (c == 16) {
+            const ConvRec* r1 = e->model.find(p + ".cv1");
+            const ConvRec* r2 = e->model.find(p + ".cv2");
+            std::vector<uint8_t> w;
+            std::vector<float> b;
+            int cout = 0, cout_pad = 0;
+            repack_conv({r1}, cin, 32, true, &w, &b, &cout, &cout_pad, &nk1, false);
+            w1 = append(w.data(), w.size()); b1 = append(b.data(), b.size() * sizeof(float));
+            repack_conv({r2}, (2 + n) * c, 16, true, &w, &b, &cout, &cout_pad, &nk2, true, 4);
+            w2 = append(w.data(), w.size()); b2 = append(b.data(), b.size() * sizeof(float));
+        }
+        if (nk2 != 2 + n) return true;
+        auto fill = [&](Op& L, int mode, const Op& A) {
+            L.c2f_mode = mode; L.c2f_c = c; L.c2f_res = shortcut ? 1 : 0; L.c2f_cat = cat;
+            L.c2f_in_co = A.in.co; L.c2f_out_co = A.pair_out.co;
+            L.c2f_x = in; L.c2f_x2 = in2; L.c2f_out = out;
+            L.c2f_w1 = w1; L.c2f_b1 = b1; L.c2f_nk1 = nk1; L.c2f_w2 = w2; L.c2f_b2 = b2; L.c2f_nk2 = nk2; L.c2f_cout2 = cv2.cout;
+            L.c2f_wA = A.pair_wA; L.c2f_bA = A.pair_bA; L.c2f_wB = A.pair_wB; L.c2f_bB = A.pair_bB;
+            L.c2f_leader_name = L.name;
+        };
+        if (n == 1) {
+            Op& A = e->ops[base + 1];
+            fill(cv1, 3, A);
+            cv1.c2f_vis = 1;
+            A.c2f_leader_name = cv1.name; A.c2f_vis = 2;
+            e->ops[base + 2].c2f_leader_name = cv1.name; e->ops[base + 2].c2f_vis = 1;
+            cv2.c2f_leader_name = cv1.name; cv2.c2f_vis = 0;
+        } else {
+            Op& A0 = e->ops[base + 1];
+            Op& A1 = e->ops[base + 3];
+            fill(cv1, 1, A0);
+            cv1.c2f_vis = 0;
+            A0.c2f_leader_name = cv1.name; A0.c2f_vis = 2;
+            e->ops[base + 2].c2f_leader_name = cv1.name; e->ops[base + 2].c2f_vis = 0;
+            fill(A1, 2, A1);
+            A1.c2f_vis = 2;
+            e->ops[base + 4].c2f_leader_name = A1.name; e->ops[base + 4].c2f_vis = 1;
+            cv2.c2f_leader_name = A1.name; cv2.c2f_vis = 0;
+        }
+        return true;
     }
 };
 
@@ -467,6 +531,10 @@ static int build_plan(zly_engine* e, std::string* err)
         e->tap_index.clear();
         for (size_t i = 0; i < e->ops.size(); ++i)
             for (size_t k = 0; k < e->ops[i].taps.size(); ++k) e->tap_index[e->ops[i].taps[k]] = std::make_pair((int)i, (int)k);
+        std::map<std::string, int> by_name;
+        for (size_t i = 0; i < e->ops.size(); ++i) by_name[e->ops[i].name] = (int)i;
+        for (Op& op : e->ops)
+            if (!op.c2f_leader_name.empty()) op.c2f_leader = by_name[op.c2f_leader_name];
     }
 
     // device allocations
@@ -540,10 +608,33 @@ static const PairPlan* pair_active(zly_engine* e, const Op& op, int n)
     return it->second.first ? &it->second.second : nullptr;
 }
 
+// Fused C2f kernel for the group led by `L` at batch n?  (plan cached per leader and batch size)
+static const C2fPlan* c2f_active(zly_engine* e, const Op& L, int n)
+{
+    if (!L.c2f_mode || e->dtype != ZLY_DTYPE_BF16 || (e->cfg.flags & ZLY_FLAG_NO_FUSION)) return nullptr;
+    if (getenv("ZLY_NO_C2F") != nullptr) return nullptr;                    // tuning / tests
+    const Buffer& b = e->bufs[(size_t)L.c2f_cat];
+    const long key = ((((long)L.c2f_c * 4 + L.c2f_mode) * 4096 + n) * 4096 + b.H) * 4096 + b.W;
+    auto it = e->c2f_plans.find(key);
+    if (it == e->c2f_plans.end()) {
+        C2fPlan pl{};
+        const bool ok = c2f_plan(L.c2f_c, L.c2f_mode, L.c2f_nk1, L.c2f_nk2, L.c2f_cout2, n, b.H, b.W, &pl);
+        it = e->c2f_plans.emplace(key, std::make_pair(ok, pl)).first;
+    }
+    return it->second.first ? &it->second.second : nullptr;
+}
+
+// is this op's work done by an active fused C2f kernel launched at another op?
+static bool c2f_covered(zly_engine* e, const Op& op, int n)
+{
+    return op.c2f_leader >= 0 && !op.c2f_mode && c2f_active(e, e->ops[(size_t)op.c2f_leader], n) != nullptr;
+}
+
 // ops that launch nothing at this batch size (second conv of a fused pair; per-level tail ops when one launch covers all)
 static bool op_is_noop(zly_engine* e, const Op& op, int n)
 {
     if (op.kind == OP_CONV && e->stem1 && op.name == "model.1") return true;     // detect paths: computed by stem_model1_kernel (booked on model.0)
+    if (op.kind == OP_CONV && c2f_covered(e, op, n)) return true;
     if (op.kind == OP_CONV && op.pair == 2) return pair_active(e, op, n) != nullptr;
     if (op.kind == OP_HEAD && op.level != 2) return !lanes_active(n) || getenv("ZLY_NO_TAIL_SPLIT") != nullptr;
     return false;
@@ -557,6 +648,29 @@ static hipError_t run_op(zly_engine* e, const Op& op, int n, const uint8_t* d_sr
     case OP_CONV: {
         const Buffer& ib = e->bufs[(size_t)op.in.buf];
         const Buffer& ob = e->bufs[(size_t)op.out.buf];
+        if (c2f_covered(e, op, n)) return hipSuccess;               // computed by the fused C2f kernel launched at its leader
+        if (const C2fPlan* pl = c2f_active(e, op, n)) {
+            const Buffer& cb = e->bufs[(size_t)op.c2f_cat];
+            const Buffer& xb = e->bufs[(size_t)op.c2f_x.buf];
+            const Buffer& ob2 = e->bufs[(size_t)op.c2f_out.buf];
+            const char* wb = (const char*)e->d_weights;
+            C2fArgs ca{};
+            ca.x = xb.ptr; ca.x_cs = xb.C; ca.x_co = op.c2f_x.co;
+            if (op.c2f_x2.buf >= 0) {
+                const Buffer& x2 = e->bufs[(size_t)op.c2f_x2.buf];
+                ca.x2 = x2.ptr; ca.x2_cs = x2.C; ca.x2_co = op.c2f_x2.co; ca.split_c = op.c2f_x.C;
+            }
+            ca.w1 = wb + op.c2f_w1; ca.b1 = (const float*)(wb + op.c2f_b1); ca.nk1 = op.c2f_nk1;
+            ca.cat = cb.ptr; ca.cat_cs = cb.C; ca.pair_in_co = op.c2f_in_co; ca.pair_out_co = op.c2f_out_co;
+            ca.wA = wb + op.c2f_wA; ca.bA = (const float*)(wb + op.c2f_bA); ca.wB = wb + op.c2f_wB; ca.bB = (const float*)(wb + op.c2f_bB);
+            ca.res = op.c2f_res;
+            ca.w2 = wb + op.c2f_w2; ca.b2 = (const float*)(wb + op.c2f_b2); ca.nk2 = op.c2f_nk2; ca.Cout2 = op.c2f_cout2;
+            ca.out = ob2.ptr; ca.out_cs = ob2.C; ca.out_co = op.c2f_out.co;
+            ca.H = cb.H; ca.W = cb.W; ca.n = n;
+            ca.TH = pl->th; ca.TW = pl->tw; ca.tiles_x = pl->tiles_x; ca.tiles_y = pl->tiles_y; ca.total_tiles = pl->total_tiles;
+            ca.dump = (e->cfg.flags & ZLY_FLAG_DUMP_LOGITS) ? 1 : 0;
+            return launch_c2f(op.c2f_c, op.c2f_mode, ca, *pl, s);
+        }
         if (op.pair) {
             const PairPlan* pl = pair_active(e, op, n);
             if (pl && op.pair == 2) return hipSuccess;             // computed by the pair kernel launched at the first conv
@@ -1218,6 +1332,7 @@ int32_t zly_create(const zly_config* cfg, zly_engine** out)
     HIP_TRY(conv_init(), ZLY_ERR_SYSTEM);
     HIP_TRY(pair_init(), ZLY_ERR_SYSTEM);
     HIP_TRY(stem1_init(), ZLY_ERR_SYSTEM);
+    HIP_TRY(c2f_init(), ZLY_ERR_SYSTEM);
 
     zly_engine* e = new zly_engine();
     e->cfg = *cfg;
@@ -1568,6 +1683,10 @@ int32_t zly_debug_tap(zly_engine* e, const char* name, int32_t idx, float* out, 
             const Op& op = e->ops[(size_t)it->second.first];
             if (e->last_stem1 && op.name == "model.0" && !(e->cfg.flags & ZLY_FLAG_DUMP_LOGITS))
                 return fail(ZLY_ERR_INVALID_ARGUMENT, "tap model.0 stays in LDS inside the fused stem kernel; create the engine with ZLY_FLAG_DUMP_LOGITS (or ZLY_FLAG_NO_FUSION)");
+            if (e->last_n > 0 && op.c2f_leader >= 0 && c2f_active(e, e->ops[(size_t)op.c2f_leader], e->last_n) &&
+                (op.c2f_vis == 2 || (op.c2f_vis == 1 && !(e->cfg.flags & ZLY_FLAG_DUMP_LOGITS))))
+                return fail(ZLY_ERR_INVALID_ARGUMENT, std::string("tap ") + name + " stays in LDS inside the fused C2f kernel at this batch size; create the engine with " +
+                                                          (op.c2f_vis == 1 ? "ZLY_FLAG_DUMP_LOGITS or " : "") + "ZLY_FLAG_NO_FUSION");
             if (op.pair == 1 && e->last_n > 0 && pair_active(e, op, e->last_n))
                 return fail(ZLY_ERR_INVALID_ARGUMENT, std::string("tap ") + name + " stays in LDS inside the fused bottleneck kernel at this batch size; create the engine with ZLY_FLAG_NO_FUSION");
             buf = op.out.buf; co = op.out.co + op.tap_co[(size_t)it->second.second]; C = op.tap_c[(size_t)it->second.second];
@@ -1625,6 +1744,11 @@ int32_t zly_op_kernel_name(zly_engine* e, int32_t i, int32_t n, char* out, size_
         if (i == 1 && e->stem1) { k = "stem_model1_kernel (preprocess+model.0+model.1)"; break; }
         if (i == 2 && e->stem1) { k = "(fused into the previous launch)"; break; }
         if (i == 1 && e->stem_fused) { k = "stem_fused_kernel"; break; }
+        if (c2f_covered(e, op, n)) { k = "(fused into the C2f kernel at " + op.c2f_leader_name + ")"; break; }
+        if (c2f_active(e, op, n)) {
+            k = "c2f_kernel<C=" + std::to_string(op.c2f_c) + (op.c2f_mode == 3 ? ",cv1+bottleneck+cv2>" : op.c2f_mode == 1 ? ",cv1+bottleneck>" : ",bottleneck+cv2>");
+            break;
+        }
         if (op.pair && pair_active(e, op, n)) { k = op.pair == 1 ? "bottleneck_pair_kernel<" + std::to_string(op.pair_c) + ">" : "(fused into the previous launch)"; break; }
         const Buffer& ob = e->bufs[(size_t)op.out.buf];
         const int cin = op.in.C + (op.in2.buf >= 0 ? op.in2.C : 0);

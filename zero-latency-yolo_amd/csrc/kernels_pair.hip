@@ -252,6 +252,308 @@ __global__ __launch_bounds__(NW * 64) void bottleneck_pair_kernel(const PairArgs
 }
 
 // ------------------------------------------------------------------------------------------------
+// C2f block around one bottleneck as ONE kernel (bf16, C = 16 / 32): ultralytics C2f = cv2(cat(chunk(cv1(x)), m_i(...))).
+//
+//   MODE 3  cv1 (1x1) -> bottleneck -> cv2 (1x1)      a whole C2f with one bottleneck (model.2, model.15): 3 launches -> 1,
+//                                                     the concat buffer never leaves LDS
+//   MODE 1  cv1 (1x1) -> bottleneck                   front half of a C2f with two bottlenecks (model.4): y0 | y1 | y2 go to
+//                                                     the concat buffer in HBM for MODE 2
+//   MODE 2  bottleneck -> cv2 (1x1)                   back half: y0 | y1 come from the concat buffer, y2 is the staged patch,
+//                                                     y3 stays in LDS
+// cv1 is pointwise, so it is simply evaluated on every pixel of the bottleneck's (TH+4) x (TW+4) input patch straight from
+// global memory (fragments = 16-byte NHWC loads, optionally dual-source: the fused Upsample+Concat of the neck), its second
+// half y1 lands in the patch buffer the 3x3 convs read, its first half y0 (tile interior only) in an LDS map for cv2.  cv2
+// takes its k-steps from the LDS maps in concat order.  Every intermediate is rounded to bf16 exactly where the unfused
+// path rounds it (bias + SiLU in fp32, then bf16), so the results match the one-kernel-per-conv path up to fp32 summation
+// order.  Halo pixels of cv1 are recomputed by neighbouring tiles (1.3-1.7x the cv1 work; these layers are bound by bytes
+// and SiLU issue, not by MFMAs).  With a.dump (debug taps) the intermediates are also written to the concat buffer.
+// ------------------------------------------------------------------------------------------------
+template <int C, int MODE, int NW, int NLD>
+__global__ __launch_bounds__(NW * 64) void c2f_kernel(const C2fArgs a)
+{
+    typedef PairGeom<C> G;
+    typedef typename G::frag F;
+    constexpr bool FRONT = (MODE & 1) != 0, BACK = (MODE & 2) != 0;
+    constexpr int NT = NW * 64;
+    constexpr int UPP = C / 8;
+    constexpr int WBYTES = 9 * G::CT * G::WTILE;          // one 3x3 conv's weights
+    constexpr int T1 = 2 * C / 16;                        // cv1 output tiles (y0 | y1)
+    constexpr int T2MAX = 4;                              // cv2 output tiles (Cout2 = 32 or 64)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int PW = a.TW + 4, PH = a.TH + 4, MW = a.TW + 2, MH = a.TH + 2;
+    const int w1_bytes = FRONT ? T1 * a.nk1 * 1024 : 0;
+    const int T2 = a.Cout2 >> 4;
+    const int w2_bytes = BACK ? T2 * a.nk2 * G::WTILE : 0;
+    unsigned char* lwA = smem;
+    unsigned char* lwB = lwA + WBYTES;
+    unsigned char* lw1 = lwB + WBYTES;
+    unsigned char* lw2 = lw1 + w1_bytes;
+    unsigned char* lin = lw2 + w2_bytes;
+    unsigned char* lmid = lin + (PH * PW * G::PITCH + 15) / 16 * 16;
+    unsigned char* ly2 = lmid + (MH * MW * G::PITCH + 15) / 16 * 16;                       // BACK: the bottleneck's output map
+    unsigned char* ly0 = ly2 + (BACK ? (a.TH * a.TW * G::PITCH + 15) / 16 * 16 : 0);      // MODE 3: first half of cv1's output
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p = lane & 15, kq = lane >> 4;
+    bf16_t* __restrict__ cat = static_cast<bf16_t*>(a.cat);
+
+    auto stage = [&](unsigned char* dst, const void* src, int bytes) {
+        for (int u = tid; u < bytes / 16; u += NT)
+            *reinterpret_cast<u32x4_t*>(dst + (size_t)u * 16) = *reinterpret_cast<const u32x4_t*>(static_cast<const unsigned char*>(src) + (size_t)u * 16);
+    };
+    stage(lwA, a.wA, WBYTES);
+    stage(lwB, a.wB, WBYTES);
+    if (FRONT) stage(lw1, a.w1, w1_bytes);
+    if (BACK) stage(lw2, a.w2, w2_bytes);
+
+    f32x4 biasA[G::CT], biasB[G::CT], bias1[T1], bias2[T2MAX];
+#pragma unroll
+    for (int c = 0; c < G::CT; ++c) {
+        const int ch = C == 16 ? kq * 4 : (c >> 1) * 32 + kq * 8 + (c & 1) * 4;
+        biasA[c] = *reinterpret_cast<const f32x4*>(a.bA + ch);
+        biasB[c] = *reinterpret_cast<const f32x4*>(a.bB + ch);
+    }
+#pragma unroll
+    for (int c = 0; c < T1; ++c) {
+        // C = 16: cv1's rows are in channel order (tile 0 = y0, tile 1 = y1); C = 32: pair-permuted (tiles 0,1 = y0, tiles 2,3 = y1)
+        const int ch = C == 16 ? c * 16 + kq * 4 : (c >> 1) * 32 + kq * 8 + (c & 1) * 4;
+        bias1[c] = FRONT ? *reinterpret_cast<const f32x4*>(a.b1 + ch) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int c = 0; c < T2MAX; ++c)
+        bias2[c] = (BACK && c < T2) ? *reinterpret_cast<const f32x4*>(a.b2 + (c >> 1) * 32 + kq * 8 + (c & 1) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const float invPW = 1.0f / (float)PW, invMW = 1.0f / (float)MW, invTW = 1.0f / (float)a.TW;
+    const int tiles_per_img = a.tiles_x * a.tiles_y;
+    const int NP0 = PH * PW, NPA = MH * MW, NPB = a.TH * a.TW;
+    const int nt0 = (NP0 + 15) >> 4, ntA = (NPA + 15) >> 4, ntB = (NPB + 15) >> 4;
+    const int NPU = NP0 * UPP;
+
+    auto tile_origin = [&](int tl, int& b, int& y0, int& x0) {
+        b = tl / tiles_per_img;
+        const int r = tl - b * tiles_per_img;
+        const int ty = r / a.tiles_x;
+        y0 = ty * a.TH; x0 = (r - ty * a.tiles_x) * a.TW;
+    };
+    // one map pixel (C channels) <- the CT accumulator tiles of a lane (same layout conv A writes)
+    auto put_map = [&](unsigned char* dst, const f32x4* o) {
+        if (C == 16) store4(reinterpret_cast<bf16_t*>(dst) + kq * 4, o[0]);
+        else store8(reinterpret_cast<bf16_t*>(dst) + kq * 8, o[0], o[1]);
+    };
+    auto put_global = [&](bf16_t* dst, const f32x4* o) {
+        if (C == 16) store4(dst + kq * 4, o[0]);
+        else store8(dst + kq * 8, o[0], o[1]);
+    };
+
+    // MODE 2: the bottleneck's input patch comes from the concat buffer (prefetched one tile ahead, as bottleneck_pair_kernel does)
+    u32x4_t pre[NLD];
+    auto stage_load = [&](int tl) {
+        int b, y0, x0;
+        tile_origin(tl, b, y0, x0);
+        const bf16_t* in = cat + a.pair_in_co;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int u = tid + i * NT;
+            u32x4_t v = {0u, 0u, 0u, 0u};
+            if (u < NPU) {
+                const int px = u / UPP, part = u - px * UPP;
+                const int py = div_small(px, invPW), pxx = px - py * PW;
+                const int gy = y0 - 2 + py, gx = x0 - 2 + pxx;
+                if ((unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W)
+                    v = *reinterpret_cast<const u32x4_t*>(in + ((size_t)(b * a.H + gy) * a.W + gx) * a.cat_cs + part * 8);
+            }
+            pre[i] = v;
+        }
+    };
+    auto stage_store = [&]() {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int u = tid + i * NT;
+            if (u < NPU) {
+                const int px = u / UPP, part = u - px * UPP;
+                *reinterpret_cast<u32x4_t*>(lin + px * G::PITCH + part * 16) = pre[i];
+            }
+        }
+    };
+
+    int tl = blockIdx.x;
+    if (tl >= a.total_tiles) return;
+    if (!FRONT) stage_load(tl);
+    while (true) {
+        int b, y0, x0;
+        tile_origin(tl, b, y0, x0);
+        const int tnext = tl + gridDim.x;
+        if (!FRONT) {
+            stage_store();
+            __syncthreads();                           // patch (and, first time, the weights) visible; previous tile's readers done
+            if (tnext < a.total_tiles) stage_load(tnext);
+        } else {
+            __syncthreads();                           // weights visible / previous tile's readers of lin, ly0 done
+            // ---- cv1 on every pixel of the patch: x (global) -> y0 | y1 ----------------------------------------------
+            const bf16_t* __restrict__ xa = static_cast<const bf16_t*>(a.x) + a.x_co;
+            const bf16_t* __restrict__ xb = static_cast<const bf16_t*>(a.x2) + a.x2_co;
+            const bool dual = a.x2 != nullptr;
+            const unsigned char* w1l = lw1 + lane * 16;
+            for (int t = wave; t < nt0; t += NW) {
+                const int q = t * 16 + p;
+                const int qc = min(q, NP0 - 1);
+                const int py = div_small(qc, invPW), px = qc - py * PW;
+                const int gy = y0 - 2 + py, gx = x0 - 2 + px;
+                const bool inimg = (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+                const size_t pa = dual ? ((size_t)(b * (a.H >> 1) + (gy >> 1)) * (a.W >> 1) + (gx >> 1)) * a.x_cs : ((size_t)(b * a.H + gy) * a.W + gx) * a.x_cs;
+                const size_t pb2 = ((size_t)(b * a.H + gy) * a.W + gx) * a.x2_cs;
+                f32x4 acc[T1];
+#pragma unroll
+                for (int c = 0; c < T1; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int s = 0; s < a.nk1; ++s) {
+                    const int ci = s * 32 + kq * 8;
+                    bf16x8 xf;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) xf[j] = (bf16_t)0.0f;
+                    if (inimg) xf = (dual && ci >= a.split_c) ? *reinterpret_cast<const bf16x8*>(xb + pb2 + (ci - a.split_c)) : *reinterpret_cast<const bf16x8*>(xa + pa + ci);
+#pragma unroll
+                    for (int c = 0; c < T1; ++c) {
+                        const bf16x8 wf = *reinterpret_cast<const bf16x8*>(w1l + (c * a.nk1 + s) * 1024);
+                        acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, acc[c], 0, 0, 0);
+                    }
+                }
+                f32x4 o[T1];
+#pragma unroll
+                for (int c = 0; c < T1; ++c) {
+                    f32x4 v = acc[c] + bias1[c];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = inimg ? silu<bf16_t>(v[r]) : 0.0f;      // outside the frame: the 3x3 convs' zero padding
+                    o[c] = v;
+                }
+                if (q < NP0) {
+                    put_map(lin + (size_t)qc * G::PITCH, o + G::CT);                          // y1: the bottleneck's input
+                    const int iy = py - 2, ix = px - 2;
+                    const bool interior = (unsigned)iy < (unsigned)a.TH && (unsigned)ix < (unsigned)a.TW && inimg;
+                    if (interior) {
+                        if (MODE == 3) put_map(ly0 + (size_t)(iy * a.TW + ix) * G::PITCH, o);
+                        if (MODE == 1 || a.dump) {
+                            bf16_t* dst = cat + ((size_t)(b * a.H + gy) * a.W + gx) * a.cat_cs;
+                            put_global(dst, o);
+                            put_global(dst + C, o + G::CT);
+                        }
+                    }
+                }
+            }
+            __syncthreads();                           // y1 patch complete
+        }
+
+        // ---- conv A: patch -> intermediate map in LDS ----------------------------------------------------------------
+        for (int t = wave; t < ntA; t += NW) {
+            const int q = t * 16 + p;
+            const int qc = min(q, NPA - 1);
+            const int my = div_small(qc, invMW), mx = qc - my * MW;
+            f32x4 acc[G::CT];
+            pair_taps<C>(lin, lwA, (my * PW + mx) * G::PITCH + kq * G::FRAGB, PW * G::PITCH, lane, acc);
+            const int gy = y0 - 1 + my, gx = x0 - 1 + mx;
+            const bool inimg = (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+            f32x4 o[G::CT];
+#pragma unroll
+            for (int c = 0; c < G::CT; ++c) {
+                f32x4 v = acc[c] + biasA[c];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = inimg ? silu<bf16_t>(v[r]) : 0.0f;
+                o[c] = v;
+            }
+            if (q < NPA) put_map(lmid + (size_t)(my * MW + mx) * G::PITCH, o);
+        }
+        __syncthreads();                               // intermediate map complete
+
+        // ---- conv B: intermediate -> y (+ shortcut from the patch) ----------------------------------------------------
+        for (int t = wave; t < ntB; t += NW) {
+            const int q = t * 16 + p;
+            const int qc = min(q, NPB - 1);
+            const int oy = div_small(qc, invTW), ox = qc - oy * a.TW;
+            f32x4 acc[G::CT];
+            pair_taps<C>(lmid, lwB, (oy * MW + ox) * G::PITCH + kq * G::FRAGB, MW * G::PITCH, lane, acc);
+            f32x4 o[G::CT];
+#pragma unroll
+            for (int c = 0; c < G::CT; ++c) {
+                f32x4 v = acc[c] + biasB[c];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = silu<bf16_t>(v[r]);
+                o[c] = v;
+            }
+            const int gy = y0 + oy, gx = x0 + ox;
+            if (q < NPB) {
+                if (a.res) {
+                    const unsigned char* xs = lin + ((oy + 2) * PW + ox + 2) * G::PITCH;
+                    if (C == 16) o[0] += load4(reinterpret_cast<const bf16_t*>(xs) + kq * 4);
+                    else { f32x4 ra, rb; load8(reinterpret_cast<const bf16_t*>(xs) + kq * 8, ra, rb); o[0] += ra; o[1 % G::CT] += rb; }
+                }
+                if (BACK) put_map(ly2 + (size_t)qc * G::PITCH, o);
+                if ((!BACK || a.dump) && gy < a.H && gx < a.W)
+                    put_global(cat + ((size_t)(b * a.H + gy) * a.W + gx) * a.cat_cs + a.pair_out_co, o);
+            }
+        }
+
+        if (BACK) {
+            __syncthreads();                           // y map complete
+            // ---- cv2 over the concat [from HBM: channels below the bottleneck's input | patch interior | y] -> out -----------
+            // k-step size = C (one source map per k-step); MODE 3: y0 comes from its LDS map instead of HBM
+            const int nglob = MODE == 2 ? a.pair_in_co / C : 0;
+            const unsigned char* w2l = lw2 + lane * G::FRAGB;
+            for (int t = wave; t < ntB; t += NW) {
+                const int q = t * 16 + p;
+                const int qc = min(q, NPB - 1);
+                const int oy = div_small(qc, invTW), ox = qc - oy * a.TW;
+                const int gy = min(y0 + oy, a.H - 1), gx = min(x0 + ox, a.W - 1);
+                const bf16_t* gp = cat + ((size_t)(b * a.H + gy) * a.W + gx) * a.cat_cs + kq * (G::FRAGB / 2);
+                f32x4 acc[T2MAX];
+#pragma unroll
+                for (int c = 0; c < T2MAX; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+                int s = 0;
+                for (; s < nglob; ++s) {
+                    const F xf = *reinterpret_cast<const F*>(gp + s * C);
+#pragma unroll
+                    for (int c = 0; c < T2MAX; ++c)
+                        if (c < T2) acc[c] = G::mma(*reinterpret_cast<const F*>(w2l + (c * a.nk2 + s) * G::WTILE), xf, acc[c]);
+                }
+                if (MODE == 3) {
+                    const F xf = *reinterpret_cast<const F*>(ly0 + (size_t)qc * G::PITCH + kq * G::FRAGB);
+#pragma unroll
+                    for (int c = 0; c < T2MAX; ++c)
+                        if (c < T2) acc[c] = G::mma(*reinterpret_cast<const F*>(w2l + (c * a.nk2 + s) * G::WTILE), xf, acc[c]);
+                    ++s;
+                }
+                {
+                    const F xf = *reinterpret_cast<const F*>(lin + (size_t)((oy + 2) * PW + ox + 2) * G::PITCH + kq * G::FRAGB);
+#pragma unroll
+                    for (int c = 0; c < T2MAX; ++c)
+                        if (c < T2) acc[c] = G::mma(*reinterpret_cast<const F*>(w2l + (c * a.nk2 + s) * G::WTILE), xf, acc[c]);
+                    ++s;
+                }
+                {
+                    const F xf = *reinterpret_cast<const F*>(ly2 + (size_t)qc * G::PITCH + kq * G::FRAGB);
+#pragma unroll
+                    for (int c = 0; c < T2MAX; ++c)
+                        if (c < T2) acc[c] = G::mma(*reinterpret_cast<const F*>(w2l + (c * a.nk2 + s) * G::WTILE), xf, acc[c]);
+                }
+                if (q < NPB && y0 + oy < a.H && x0 + ox < a.W) {
+                    bf16_t* dst = static_cast<bf16_t*>(a.out) + ((size_t)(b * a.H + gy) * a.W + gx) * a.out_cs + a.out_co;
+#pragma unroll
+                    for (int g2 = 0; g2 < T2MAX / 2; ++g2) {
+                        if (2 * g2 >= T2) break;
+                        f32x4 lo = acc[2 * g2] + bias2[2 * g2], hi = acc[2 * g2 + 1] + bias2[2 * g2 + 1];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { lo[r] = silu<bf16_t>(lo[r]); hi[r] = silu<bf16_t>(hi[r]); }
+                        store8(dst + g2 * 32 + kq * 8, lo, hi);
+                    }
+                }
+            }
+        }
+        if (tnext >= a.total_tiles) break;
+        tl = tnext;
+        if (!FRONT) __syncthreads();                   // all reads of the patch / maps done before stage_store overwrites them (FRONT: barrier at loop top)
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 // waves per workgroup: c = 32 keeps a conv's 18 weight fragments in registers across its pixel-tile loop (the compiler hoists the
@@ -303,6 +605,79 @@ hipError_t pair_init()
     r = hipFuncSetAttribute((const void*)bottleneck_pair_kernel<32, PAIR_NW32, PAIR_NLD>, hipFuncAttributeMaxDynamicSharedMemorySize, PAIR_LDS_MAX);
     if (r != hipSuccess) return r;
     return hipFuncSetAttribute((const void*)bottleneck_pair_kernel<64, PAIR_NW64, PAIR_NLD64>, hipFuncAttributeMaxDynamicSharedMemorySize, PAIR_LDS_MAX);
+}
+
+// ---- fused C2f kernel -----------------------------------------------------------------------------------------------
+static constexpr int C2F_NW16 = 16, C2F_NW32 = 8, C2F_NLD = 4;
+static size_t c2f_lds_bytes(int c, int mode, int nk1, int nk2, int cout2, int th, int tw)
+{
+    const size_t pitch = (size_t)pair_pitch(c), wtile = c == 16 ? 512 : 1024, ct = c / 16;
+    size_t b = 2 * 9 * ct * wtile;
+    if (mode & 1) b += (size_t)(2 * c / 16) * nk1 * 1024;
+    if (mode & 2) b += (size_t)(cout2 / 16) * nk2 * wtile;
+    b += ((size_t)(th + 4) * (tw + 4) * pitch + 15) / 16 * 16 + ((size_t)(th + 2) * (tw + 2) * pitch + 15) / 16 * 16;
+    if (mode & 2) b += ((size_t)th * tw * pitch + 15) / 16 * 16;
+    if (mode == 3) b += ((size_t)th * tw * pitch + 15) / 16 * 16;
+    return b;
+}
+
+// tile shape: rounds of tiles over the CUs x (16-pixel tile rounds of the phases over the workgroup's waves + a fixed cost), LDS budget
+bool c2f_plan(int c, int mode, int nk1, int nk2, int cout2, int n, int H, int W, C2fPlan* plan)
+{
+    if ((c != 16 && c != 32) || mode < 1 || mode > 3) return false;
+    const int ncu = num_cus(), nw = c == 16 ? C2F_NW16 : C2F_NW32;
+    double best = 1e30;
+    for (int th = 4; th <= 32; ++th) {
+        for (int tw = 8; tw <= 64; ++tw) {
+            if (c2f_lds_bytes(c, mode, nk1, nk2, cout2, th, tw) > (size_t)PAIR_LDS_MAX) continue;
+            if (!(mode & 1) && (th + 4) * (tw + 4) * (c / 8) > nw * 64 * C2F_NLD) continue;
+            const int tx = (W + tw - 1) / tw, ty = (H + th - 1) / th;
+            const long tiles = (long)n * tx * ty;
+            const long rounds = (tiles + ncu - 1) / ncu;
+            const int nt0 = ((th + 4) * (tw + 4) + 15) / 16, ntA = ((th + 2) * (tw + 2) + 15) / 16, ntB = (th * tw + 15) / 16;
+            const int ct = c / 16;
+            // phase weights in units of one 3x3 conv tile round (9 x CT MFMAs + CT epilogue tiles)
+            const double w_cv1 = (double)(2 * ct * nk1 + 2.0 * 2 * ct) / (9.0 * ct + 2.0 * ct);
+            const double w_cv2 = (double)((cout2 / 16) * nk2 + 2.0 * (cout2 / 16)) / (9.0 * ct + 2.0 * ct);
+            double per_tile = (double)((ntA + nw - 1) / nw + (ntB + nw - 1) / nw) + 1.5 * 16 / nw;
+            if (mode & 1) per_tile += w_cv1 * ((nt0 + nw - 1) / nw);
+            if (mode & 2) per_tile += w_cv2 * ((ntB + nw - 1) / nw);
+            const double cost = (double)rounds * per_tile;
+            if (cost < best) { best = cost; plan->th = th; plan->tw = tw; plan->tiles_x = tx; plan->tiles_y = ty; plan->total_tiles = (int)tiles; }
+        }
+    }
+    if (best >= 1e30) return false;
+    plan->grid = plan->total_tiles < ncu ? plan->total_tiles : ncu;
+    plan->lds_bytes = (int)c2f_lds_bytes(c, mode, nk1, nk2, cout2, plan->th, plan->tw);
+    return true;
+}
+
+typedef void (*c2f_fn)(const C2fArgs);
+static c2f_fn pick_c2f(int c, int mode)
+{
+    if (c == 16) return mode == 1 ? c2f_kernel<16, 1, C2F_NW16, C2F_NLD> : mode == 2 ? c2f_kernel<16, 2, C2F_NW16, C2F_NLD> : c2f_kernel<16, 3, C2F_NW16, C2F_NLD>;
+    return mode == 1 ? c2f_kernel<32, 1, C2F_NW32, C2F_NLD> : mode == 2 ? c2f_kernel<32, 2, C2F_NW32, C2F_NLD> : c2f_kernel<32, 3, C2F_NW32, C2F_NLD>;
+}
+
+hipError_t c2f_init()
+{
+    for (int c = 16; c <= 32; c += 16)
+        for (int mode = 1; mode <= 3; ++mode) {
+            hipError_t r = hipFuncSetAttribute((const void*)pick_c2f(c, mode), hipFuncAttributeMaxDynamicSharedMemorySize, PAIR_LDS_MAX);
+            if (r != hipSuccess) return r;
+        }
+    return hipSuccess;
+}
+
+hipError_t launch_c2f(int c, int mode, const C2fArgs& a, const C2fPlan& plan, hipStream_t s)
+{
+    if ((c != 16 && c != 32) || mode < 1 || mode > 3 || a.TH != plan.th || a.TW != plan.tw || plan.grid < 1) return hipErrorInvalidValue;
+    if (a.cat_cs % 8 || a.pair_in_co % c || a.pair_out_co % c || a.out_cs % 8 || a.out_co % 8) return hipErrorInvalidValue;
+    if ((mode & 1) && (a.x_cs % 8 || a.x_co % 8 || (a.x2 && (a.x2_cs % 8 || a.x2_co % 8 || a.split_c % 32 || (a.H & 1) || (a.W & 1))))) return hipErrorInvalidValue;
+    if ((mode & 2) && (a.Cout2 % 32 || a.Cout2 > 64)) return hipErrorInvalidValue;
+    const int nw = c == 16 ? C2F_NW16 : C2F_NW32;
+    hipLaunchKernelGGL(pick_c2f(c, mode), dim3((unsigned)plan.grid), dim3(nw * 64), (size_t)plan.lds_bytes, s, a);
+    return hipGetLastError();
 }
 
 hipError_t launch_pair(int c, const PairArgs& a, const PairPlan& plan, hipStream_t s)

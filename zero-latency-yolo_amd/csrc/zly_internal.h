@@ -69,6 +69,25 @@ bool       pair_plan(int c, int n, int H, int W, PairPlan* plan);
 hipError_t pair_init();
 hipError_t launch_pair(int c, const PairArgs& a, const PairPlan& plan, hipStream_t s);
 
+// a C2f block around one bottleneck as one kernel (kernels_pair.hip: c2f_kernel); mode bit 0 = cv1 in front, bit 1 = cv2 behind
+struct C2fArgs {
+    const void* x;  int x_cs, x_co;           // cv1 input (NHWC view); with x2 set: the half-size tensor of a fused Upsample+Concat
+    const void* x2; int x2_cs, x2_co, split_c;
+    const void* w1; const float* b1; int nk1; // cv1: tiled [2C/16][nk1][lane][8] (k-steps of 32); C = 16: rows in channel order, C = 32: pair-permuted
+    void* cat; int cat_cs;                    // the C2f's concat buffer in HBM: [y0 | y1 | y2 | ...], C channels each
+    int pair_in_co, pair_out_co;              // channel offsets of the bottleneck's input / output inside cat
+    const void* wA; const float* bA; const void* wB; const float* bB; int res;     // the bottleneck (as PairArgs)
+    const void* w2; const float* b2; int nk2, Cout2;   // cv2: tiled [Cout2/16][nk2][lane][frag], k-steps of C in concat order, pair-permuted rows
+    void* out; int out_cs, out_co;
+    int H, W, n;
+    int TH, TW, tiles_x, tiles_y, total_tiles;
+    int dump;                                 // also write the intermediates that would stay in LDS to cat (debug taps)
+};
+struct C2fPlan { int th, tw, tiles_x, tiles_y, total_tiles, grid, lds_bytes; };
+bool       c2f_plan(int c, int mode, int nk1, int nk2, int cout2, int n, int H, int W, C2fPlan* plan);
+hipError_t c2f_init();
+hipError_t launch_c2f(int c, int mode, const C2fArgs& a, const C2fPlan& plan, hipStream_t s);
+
 // kernels_misc.hip
 hipError_t launch_preprocess(int dtype, const uint8_t* src, const FrameDesc* desc, int n,
                              void* out_nhwc8, float* out_nchw_f32, int tw, int th, hipStream_t s);
