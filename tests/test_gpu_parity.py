@@ -805,8 +805,10 @@ def test_fused_c2f_blocks(weights_path, oracle, w, h, n):
             _assert_layer_close(g, ref.taps[name][i].numpy(), f"{name}[{i}] vs oracle")
             if n >= 16 and not name.startswith("model.2."):
                 assert np.array_equal(g, t), (name, i, float(np.mean(g != t)))
-            else:
+            elif name.startswith("model.2."):          # the first fused block sees identical inputs in both engines: rare last-bit flips only
                 assert np.abs(g - t).max() <= 2.0 ** -6 * np.abs(t).max() and np.mean(g != t) < 0.05, (name, i)
+            else:                                      # small batches: the unfused engine splits K across waves, flips propagate downstream
+                assert np.abs(g - t).max() <= 2.0 ** -5 * np.abs(t).max(), (name, i)
     _assert_bf16_close(hf, hp)
     e.close()
     # without the dumps the LDS-resident intermediates cannot be tapped, the block outputs can, and the results are the same
