@@ -898,6 +898,7 @@ static bool pick_stream_config(int cin, int cout_pad, int M, ConvLaunch* cfg)
     else if (nk <= 4 && ntiles % 4 == 0) { ct = 4; pt = 2; }
     else if ((nk == 6 || nk == 8) && ntiles % 2 == 0) { ct = 2; pt = 1; }
     if (!ct || !pick_stream(ct, pt, nk)) return false;
+    if (const char* mx = getenv("ZLY_STREAM_MAX_NK")) { if (nk > atoi(mx)) return false; }          // tuning aid
     const char* mg = getenv("ZLY_STREAM_MIN_GROUPS");                     // tuning / tests: force the streaming kernel onto small launches
     if ((long)M / (16 * pt) * (ntiles / ct) < (mg ? atol(mg) : 4096)) return false;   // too few pixel groups to keep persistent waves busy
     cfg->stream = 1; cfg->ct = ct; cfg->pt = pt; cfg->ksplit = 1; cfg->fastk = 0; cfg->lds = 0;
@@ -933,11 +934,15 @@ void conv_pick_direct(int dtype, int ks, int cin, int cout_pad, int M, ConvLaunc
     const long wgs_pt1 = ((long)(M + 63) / 64) * ytiles;
     const char* e4 = getenv("ZLY_DIRECT_PT4_MIN");                       // tuning aids
     const char* e2 = getenv("ZLY_DIRECT_PT2_MIN");
-    if (wgs_pt4 >= (e4 ? atol(e4) : 1024) && cfg->ct <= 4) { cfg->pt = 4; return; }       // CT=5 x PT=4 would need > 200 VGPRs
-    if (wgs_pt2 >= (e2 ? atol(e2) : 256)) { cfg->pt = 2; return; }                      // 1024 before: the K-heavy 1x1 layers at 26x26 re-read their weights per 16 pixels (+0.8 %)
-    cfg->pt = 1;
     const int nk = (ks * ks * cin + kstep - 1) / kstep;
-    if (wgs_pt1 >= 512 || nk < 4) return;
+    const char* fk = getenv("ZLY_DIRECT_KSPLIT_NK");                   // tuning aid: K-heavy launches take the 4-way split-K shape whatever their size
+    const bool force_split = fk && nk >= atoi(fk);
+    if (!force_split) {
+        if (wgs_pt4 >= (e4 ? atol(e4) : 1024) && cfg->ct <= 4) { cfg->pt = 4; return; }       // CT=5 x PT=4 would need > 200 VGPRs
+        if (wgs_pt2 >= (e2 ? atol(e2) : 256)) { cfg->pt = 2; return; }                      // 1024 before: the K-heavy 1x1 layers at 26x26 re-read their weights per 16 pixels (+0.8 %)
+    }
+    cfg->pt = 1;
+    if (!force_split && (wgs_pt1 >= 512 || nk < 4)) return;
     cfg->ksplit = 4;                                                 // workgroup = one 16-pixel tile
     long wgs = ((long)(M + 15) / 16) * ytiles;
     while (wgs < 256 && cfg->ct > 1) {                               // still thin: fewer channel tiles per wave
