@@ -225,6 +225,8 @@ def run():
     ap.add_argument("--eager", action="store_true", help="no hipGraph replay")
     ap.add_argument("--keep-head", action="store_true", help="also materialise the fp32 [4+nc][N] head tensor (parity/debug output; the shipped plugin does not)")
     ap.add_argument("--size", type=int, default=416, help="square model/frame size; 640 = BASELINE configs[3] (then only the headline leg runs)")
+    ap.add_argument("--scale", default="n", choices=["n", "s"], help="model scale; s + --fp8 + --size 640 = BASELINE configs[4] per GPU (then only the headline leg runs)")
+    ap.add_argument("--fp8", action="store_true", help="weights stored as fp8 e4m3 (dequantised at load; the engine computes in bf16)")
     ap.add_argument("--sync-nms", action="store_true", help="run NMS in stream order at the end of every step instead of beside the next step's first kernels")
     ap.add_argument("--dump-ops", default="", help="write the per-op hipEvent profile (name, ms, GFLOP, GB, TFLOP/s, GB/s) to this file")
     a = ap.parse_args()
@@ -248,9 +250,17 @@ def run():
 
     B = a.batch
     big = 64
-    if a.size != 416:
+    if a.size != 416 or a.scale != "n" or a.fp8:
         a.no_extras = True
-    eng = zly.Engine(dtype=zly.DTYPE_BF16, model_w=a.size, model_h=a.size, max_batch=max(B, big), max_dets=64, device=local_rank, warmup_runs=3,
+    wpath = None
+    if a.scale != "n" or a.fp8:
+        wpath = os.path.join(ROOT, "zero-latency-yolo_amd", "_build", f"yolov8{a.scale}_synth{'_fp8' if a.fp8 else ''}.zlyw")
+        if rank == 0 and not os.path.exists(wpath):
+            spec_ = zm.build_spec(a.scale)
+            zm.write_zlyw(wpath, spec_, zm.synth_weights(spec_), fp8=a.fp8)
+        if world > 1:
+            dist.barrier()
+    eng = zly.Engine(wpath, dtype=zly.DTYPE_BF16, model_w=a.size, model_h=a.size, max_batch=max(B, big), max_dets=64, device=local_rank, warmup_runs=3,
                      use_graph=not a.eager, flags=(0 if a.keep_head else zly.FLAG_NO_HEAD_TENSOR) | (0 if a.sync_nms else zly.FLAG_ASYNC_NMS))
     # a real (non-default) torch stream: the engine enqueues on it, and torch.distributed orders the RCCL
     # all-gather of the slabs behind it (with the legacy default stream the engine would fall back to its
@@ -281,7 +291,7 @@ def run():
         "metric": "frames_per_sec", "value": round(value, 1), "unit": "frames/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 5),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"YOLOv8-nano {a.size}x{a.size} batch={B} streaming throughput path, bf16, per MI355X, frames resident in HBM, "
+        "config": {"workload": f"YOLOv8-{'nano' if a.scale == 'n' else 'small'} {a.size}x{a.size} batch={B} streaming throughput path, bf16{' (fp8 e4m3 weight file)' if a.fp8 else ''}, per MI355X, frames resident in HBM, "
                                f"preprocess+forward+decode+NMS per step" + (", slabs all-gathered over RCCL" if world > 1 else ""),
                    "frames_per_step_per_gpu": B, "global_frames_per_step": world * B, "conf": 0.5, "iou": 0.45,
                    "weights": "seeded synthetic (no real weights offline)", "graph": not a.eager,

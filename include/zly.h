@@ -200,6 +200,9 @@ int32_t zly_debug_tap(zly_engine* e, const char* name, int32_t idx, float* out, 
 
 /* --- introspection / measurement ------------------------------------------------------------- */
 int32_t zly_num_classes(const zly_engine* e);
+/* 1 when the model file stores its weights as fp8 e4m3 (+ per-output-channel power-of-two exponents; BASELINE configs[4]): they are
+ * dequantised once at load -- exactly representable in bf16 -- and the engine computes in bf16 as with any other file */
+int32_t zly_weights_fp8(const zly_engine* e);
 int32_t zly_num_anchors(const zly_engine* e);
 int32_t zly_num_ops(const zly_engine* e);
 int32_t zly_op_info_at(const zly_engine* e, int32_t i, zly_op_info* out);

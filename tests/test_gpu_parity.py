@@ -606,6 +606,37 @@ def test_yolov8s_widths(tmp_path, oracle):
     e.close()
 
 
+def test_yolov8s_640_fp8_weights(tmp_path, oracle):
+    """BASELINE configs[4] as one GPU sees it: YOLOv8-s, 640 x 640, fp8 (e4m3) weights.  The file stores one byte per weight; the
+    loader dequantises to values that are exact in bf16, so the engine must match the oracle ON THE SAME DEQUANTISED WEIGHTS at
+    the usual bf16 tolerances: every conv output against the bf16-rounding oracle, the head tensor against the fp32 oracle
+    (box <= 1.5 px, score <= 2e-2), detect() == the oracle's post-processing of the engine's own head tensor."""
+    import yolov8_ref
+    spec = zm.build_spec("s")
+    p = str(tmp_path / "yolov8s_synth_fp8.zlyw")
+    zm.write_zlyw(p, spec, zm.synth_weights(spec, seed=9), fp8=True)
+    ref32, ref16 = yolov8_ref.load(p, "fp32"), yolov8_ref.load(p, "bf16")
+    frames = zm.synth_frames(2, 640, 640, seed=11, rects=False)
+    x = _pre(oracle, frames, 640, 640)
+    want32 = ref32.forward(torch.from_numpy(x)).numpy()
+    want16 = ref16.forward(torch.from_numpy(x)).numpy()
+    assert want32.shape == (2, 84, 8400)
+    e = zly.Engine(p, model_w=640, model_h=640, max_batch=2, max_dets=1024, conf_thr=0.9, warmup_runs=0, flags=zly.FLAG_DUMP_LOGITS)
+    assert e.weights_fp8
+    got = e.forward(x)
+    _assert_bf16_close(got, want16)
+    _assert_bf16_close(got, want32)
+    assert len(_check_taps(e, ref16, (0, 1), skip_ok=(".m.0.cv1", ".m.1.cv1"))) >= 55
+    for i, f in enumerate(frames):
+        dets, n = e.detect(f, cap=1024)
+        own = oracle.postprocess(e.head_tensor(0), 640, 640, 0.9, 0.45)
+        assert n == len(own) and det_fields_equal(dets, own[:1024])
+    e.close()
+    e = zly.Engine(zly.DEFAULT_WEIGHTS, warmup_runs=0)
+    assert not e.weights_fp8
+    e.close()
+
+
 def test_production_flags_same_detections(weights_path):
     """ZLY_FLAG_NO_HEAD_TENSOR (what the plugin and bench.py run): the Detect kernel skips the fp32 head tensor, the
     detections are the same bytes; the parity entry points that need the tensor fail loudly."""

@@ -1714,6 +1714,7 @@ int32_t zly_debug_tap(zly_engine* e, const char* name, int32_t idx, float* out, 
 }
 
 int32_t zly_num_classes(const zly_engine* e) { return e ? e->nc : 0; }
+int32_t zly_weights_fp8(const zly_engine* e) { return (e && e->model.fp8_weights) ? 1 : 0; }
 int32_t zly_num_anchors(const zly_engine* e) { return e ? e->N : 0; }
 int32_t zly_num_ops(const zly_engine* e) { return e ? (int32_t)e->ops.size() : 0; }
 

@@ -4,6 +4,7 @@
 #include "weights.h"
 #include "zly.h"
 
+#include <math.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -20,7 +21,7 @@ struct FileHeader {
 };
 struct FileRec {
     char name[48];
-    uint32_t cin, cout, k, stride, act, pad;
+    uint32_t cin, cout, k, stride, act, wfmt;     // wfmt: 0 = fp32 weights, 1 = fp8 e4m3 + one int8 power-of-two exponent per output channel
     uint64_t w_off, b_off;
 };
 #pragma pack(pop)
@@ -57,6 +58,7 @@ int load_zlyw(const char* path, ModelFile* out, std::string* err)
     for (int i = 0; i < 5; ++i) out->ch[i] = (int)h.ch[i];
     for (int i = 0; i < 8; ++i) out->n_c2f[i] = (int)h.n_c2f[i];
     out->convs.clear();
+    out->fp8_weights = false;
     out->convs.reserve(h.num_convs);
     for (uint32_t i = 0; i < h.num_convs; ++i) {
         FileRec r;
@@ -72,17 +74,43 @@ int load_zlyw(const char* path, ModelFile* out, std::string* err)
         const bool dims_ok = c.cin > 0 && c.cout > 0 && c.cin <= 65536 && c.cout <= 65536 && (c.k == 1 || c.k == 3) && (c.stride == 1 || c.stride == 2);
         const size_t nw = dims_ok ? (size_t)c.cout * c.cin * c.k * c.k : 0;
         const size_t fsz = data.size();
-        if (!dims_ok || r.w_off > fsz || nw * 4 > fsz - r.w_off || r.b_off > fsz || (size_t)c.cout * 4 > fsz - r.b_off) {
+        // payload: fp32 [cout][cin][k][k], or (wfmt 1) int8 exponent[cout] padded to 4 bytes, then e4m3 [cout][cin][k][k]
+        const size_t exp_bytes = dims_ok ? ((size_t)c.cout + 3) / 4 * 4 : 0;
+        const size_t wbytes = r.wfmt == 1 ? exp_bytes + nw : nw * 4;
+        if (!dims_ok || r.wfmt > 1 || r.w_off > fsz || wbytes > fsz - r.w_off || r.b_off > fsz || (size_t)c.cout * 4 > fsz - r.b_off) {
             *err = "corrupt conv record: " + c.name;
             return ZLY_ERR_MODEL_LOAD;
         }
         c.w.resize(nw);
         c.b.resize((size_t)c.cout);
+        if (r.wfmt == 1) {
+            // dequantised here, once: w = e4m3 * 2^exp[cout].  3 mantissa bits times a power of two is exact in bf16, so the bf16
+            // engine computes with exactly these values (fp8 storage, bf16 MFMA: see DESIGN.md "fp8 weights")
+            const int8_t* ex = reinterpret_cast<const int8_t*>(data.data() + r.w_off);
+            const uint8_t* q = data.data() + r.w_off + exp_bytes;
+            const size_t per = nw / (size_t)c.cout;
+            for (int co = 0; co < c.cout; ++co) {
+                const float sc = ldexpf(1.0f, ex[co]);
+                for (size_t i = 0; i < per; ++i) c.w[(size_t)co * per + i] = fp8_e4m3_to_f32(q[(size_t)co * per + i]) * sc;
+            }
+            out->fp8_weights = true;
+        } else
         memcpy(c.w.data(), data.data() + r.w_off, nw * 4);
         memcpy(c.b.data(), data.data() + r.b_off, (size_t)c.cout * 4);
         out->convs.push_back(std::move(c));
     }
     return ZLY_OK;
+}
+
+// OCP fp8 e4m3 (e4m3fn: bias 7, no infinities, 0x7f / 0xff = NaN, subnormals m/8 * 2^-6) -> float
+float fp8_e4m3_to_f32(uint8_t v)
+{
+    const int sign = v >> 7, ex = (v >> 3) & 15, man = v & 7;
+    float mag;
+    if (ex == 15 && man == 7) { uint32_t nan = 0x7fc00000u; memcpy(&mag, &nan, 4); return mag; }
+    if (ex == 0) mag = (float)man * (1.0f / 512.0f);                   // man/8 * 2^-6
+    else { uint32_t bits = ((uint32_t)(ex - 7 + 127) << 23) | ((uint32_t)man << 20); memcpy(&mag, &bits, 4); }
+    return sign ? -mag : mag;
 }
 
 uint16_t f32_to_bf16_rne(float f)

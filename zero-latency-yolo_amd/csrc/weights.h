@@ -15,6 +15,7 @@ struct ConvRec {
 
 struct ModelFile {
     int nc = 0, reg_max = 0;
+    bool fp8_weights = false;     // at least one conv is stored as fp8 e4m3 (BASELINE configs[4])
     int ch[5] = {0, 0, 0, 0, 0};
     int n_c2f[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     std::vector<ConvRec> convs;
@@ -25,6 +26,7 @@ struct ModelFile {
 int load_zlyw(const char* path, ModelFile* out, std::string* err);
 
 uint16_t f32_to_bf16_rne(float f);
+float fp8_e4m3_to_f32(uint8_t v);
 
 // Concatenates `srcs` along cout and lays the result out as the conv kernel reads it:
 //   [cout_pad/16][nk][lane = (kk/epl)*16 + row][epl] with k = (ky*ks + kx)*cin_store + ci = step*kstep + kk,

@@ -355,6 +355,7 @@ std::unordered_map<std::string, std::string> HipInferenceEngine::getStatus() con
     s["avg_preprocessing_time_ms"] = frames ? std::to_string(pre / (double)frames) : "0";
     s["avg_forward_time_ms"] = frames ? std::to_string(fwd / (double)frames) : "0";
     s["avg_postprocessing_time_ms"] = frames ? std::to_string(post / (double)frames) : "0";
+    s["weight_format"] = (!engines.empty() && zly_weights_fp8(engines[0]->e)) ? "fp8_e4m3" : "fp32";      // the reference's "quantised" model claim (README.md:84)
     s["worker_threads"] = std::to_string(engines.size());
     s["devices"] = std::to_string(engines.size());
     return s;

@@ -11,8 +11,9 @@ real-weights loader can fill the same file format.
 
 ZLYW file (little endian), consumed by csrc/weights.cpp:
     magic "ZLYW", u32 version=1, u32 nc, u32 reg_max, u32 ch[5], u32 n_c2f[8], u32 num_convs,
-    then num_convs records {char name[48]; u32 cin, cout, k, stride, act; u32 pad; u64 w_off, b_off},
-    then fp32 payloads: weight [cout][cin][k][k] (PyTorch order) and bias [cout] per conv.
+    then num_convs records {char name[48]; u32 cin, cout, k, stride, act; u32 wfmt; u64 w_off, b_off},
+    then payloads per conv: weight [cout][cin][k][k] (PyTorch order) as fp32 (wfmt 0) or as OCP fp8 e4m3 bytes preceded by one int8
+    power-of-two exponent per output channel, padded to 4 bytes (wfmt 1: w = e4m3 * 2^exp[cout]); bias [cout] fp32.
 """
 from __future__ import annotations
 
@@ -154,7 +155,43 @@ def conv_output_sizes(spec: ModelSpec, w: int, h: int) -> List[Tuple[int, int]]:
 # file I/O
 # ----------------------------------------------------------------------------------------------
 
-def write_zlyw(path: str, spec: ModelSpec, weights: Dict[str, Tuple[np.ndarray, np.ndarray]]) -> None:
+def _e4m3_table() -> np.ndarray:
+    """the 256 OCP fp8 e4m3 (e4m3fn) values, NaN at 0x7f / 0xff"""
+    v = np.arange(256, dtype=np.uint32)
+    ex, man = (v >> 3) & 15, v & 7
+    mag = np.where(ex == 0, man / 8.0 * 2.0 ** -6, (1.0 + man / 8.0) * 2.0 ** (ex.astype(np.float64) - 7))
+    mag = np.where((ex == 15) & (man == 7), np.nan, mag)
+    return np.where(v >> 7 == 1, -mag, mag).astype(np.float32)
+
+
+E4M3 = _e4m3_table()
+E4M3_MAX = 448.0
+
+
+def quantize_fp8(w: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """fp32 [cout][...] -> (int8 exponent per output channel, uint8 e4m3 codes): w ~ e4m3 * 2^exp, the exponent chosen so that the
+    channel's largest weight lands in [224, 448]; round to nearest, ties to even code (fp8 weights, BASELINE configs[4])."""
+    flat = w.reshape(w.shape[0], -1).astype(np.float64)
+    amax = np.abs(flat).max(1)
+    ex = np.where(amax > 0, np.ceil(np.log2(np.maximum(amax, 1e-30) / E4M3_MAX)), 0).astype(np.int64)
+    ex = np.clip(ex, -126, 126)
+    x = flat / (2.0 ** ex)[:, None]
+    pos = E4M3[:127].astype(np.float64)                        # codes 0x00..0x7e ascending
+    a = np.minimum(np.abs(x), E4M3_MAX)
+    hi = np.clip(np.searchsorted(pos, a, side="left"), 1, 126)
+    lo = hi - 1
+    dlo, dhi = a - pos[lo], pos[hi] - a
+    code = np.where((dhi < dlo) | ((dhi == dlo) & (hi % 2 == 0)), hi, lo).astype(np.uint8)
+    code = np.where(x < 0, code | 0x80, code).astype(np.uint8)
+    return ex.astype(np.int8), code.reshape(w.shape)
+
+
+def dequantize_fp8(ex: np.ndarray, code: np.ndarray) -> np.ndarray:
+    return (E4M3[code].reshape(code.shape[0], -1) * (2.0 ** ex.astype(np.float64))[:, None].astype(np.float32)).reshape(code.shape).astype(np.float32)
+
+
+def write_zlyw(path: str, spec: ModelSpec, weights: Dict[str, Tuple[np.ndarray, np.ndarray]], fp8: bool = False) -> None:
+    """fp8 = True: every conv's weights are stored as e4m3 codes + per-output-channel power-of-two exponents (1 byte per weight)."""
     recs = []
     off = HDR_SIZE + REC_SIZE * len(spec.convs)
     blobs = []
@@ -162,12 +199,18 @@ def write_zlyw(path: str, spec: ModelSpec, weights: Dict[str, Tuple[np.ndarray, 
         w, b = weights[c.name]
         assert w.shape == (c.cout, c.cin, c.k, c.k) and w.dtype == np.float32, (c.name, w.shape)
         assert b.shape == (c.cout,) and b.dtype == np.float32
+        if fp8:
+            ex, code = quantize_fp8(w)
+            wblob = ex.tobytes() + b"\0" * ((-len(ex)) % 4) + np.ascontiguousarray(code).tobytes()
+        else:
+            wblob = np.ascontiguousarray(w).tobytes()
+        wblob += b"\0" * ((-len(wblob)) % 4)
         w_off = off
-        off += w.nbytes
+        off += len(wblob)
         b_off = off
         off += b.nbytes
-        recs.append(struct.pack(REC_FMT, c.name.encode(), c.cin, c.cout, c.k, c.stride, c.act, 0, w_off, b_off))
-        blobs.append(np.ascontiguousarray(w).tobytes())
+        recs.append(struct.pack(REC_FMT, c.name.encode(), c.cin, c.cout, c.k, c.stride, c.act, 1 if fp8 else 0, w_off, b_off))
+        blobs.append(wblob)
         blobs.append(np.ascontiguousarray(b).tobytes())
     hdr = struct.pack(HDR_FMT, MAGIC, VERSION, spec.nc, spec.reg_max, *spec.ch, *spec.n_c2f, len(spec.convs))
     with open(path, "wb") as f:
@@ -191,10 +234,15 @@ def read_zlyw(path: str):
     num = vals[17]
     convs, weights = [], {}
     for i in range(num):
-        name, cin, cout, k, stride, act, _pad, w_off, b_off = struct.unpack_from(REC_FMT, data, HDR_SIZE + i * REC_SIZE)
+        name, cin, cout, k, stride, act, wfmt, w_off, b_off = struct.unpack_from(REC_FMT, data, HDR_SIZE + i * REC_SIZE)
         name = name.rstrip(b"\0").decode()
         convs.append(ConvSpec(name, cin, cout, k, stride, act))
-        w = np.frombuffer(data, dtype="<f4", count=cout * cin * k * k, offset=w_off).reshape(cout, cin, k, k)
+        if wfmt == 1:
+            ex = np.frombuffer(data, dtype=np.int8, count=cout, offset=w_off)
+            code = np.frombuffer(data, dtype=np.uint8, count=cout * cin * k * k, offset=w_off + (cout + 3) // 4 * 4).reshape(cout, cin, k, k)
+            w = dequantize_fp8(ex, code)
+        else:
+            w = np.frombuffer(data, dtype="<f4", count=cout * cin * k * k, offset=w_off).reshape(cout, cin, k, k)
         b = np.frombuffer(data, dtype="<f4", count=cout, offset=b_off)
         weights[name] = (w, b)
     meta = dict(nc=nc, reg_max=reg_max, ch=ch, n_c2f=n_c2f, convs=tuple(convs))
@@ -357,11 +405,12 @@ def main(argv=None) -> int:
     ap.add_argument("--scale", default="n", choices=sorted(SCALES))
     ap.add_argument("--nc", type=int, default=80)
     ap.add_argument("--seed", type=int, default=SYNTH_SEED)
+    ap.add_argument("--fp8", action="store_true", help="store the weights as fp8 e4m3 + per-output-channel power-of-two exponents")
     ap.add_argument("-o", "--out", required=True)
     a = ap.parse_args(argv)
     spec = build_spec(a.scale, a.nc)
-    write_zlyw(a.out, spec, synth_weights(spec, a.seed))
-    print(f"{a.out}: yolov8{a.scale} nc={a.nc} convs={len(spec.convs)} params={spec.params()}")
+    write_zlyw(a.out, spec, synth_weights(spec, a.seed), fp8=a.fp8)
+    print(f"{a.out}: yolov8{a.scale} nc={a.nc} convs={len(spec.convs)} params={spec.params()}" + (" fp8-e4m3 weights" if a.fp8 else ""))
     return 0
 
 

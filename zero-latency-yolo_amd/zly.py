@@ -36,7 +36,7 @@ SYMBOLS = [
     "zly_default_config", "zly_create", "zly_destroy", "zly_last_error", "zly_version",
     "zly_detect", "zly_detect_batch", "zly_submit", "zly_poll", "zly_wait", "zly_detect_device", "zly_slab_bytes", "zly_read_slabs", "zly_sync", "zly_join",
     "zly_preprocess", "zly_forward", "zly_head_tensor", "zly_postprocess", "zly_debug_tap",
-    "zly_num_classes", "zly_num_anchors", "zly_num_ops", "zly_op_info_at", "zly_op_kernel_name", "zly_profile_ops", "zly_get_stats",
+    "zly_num_classes", "zly_weights_fp8", "zly_num_anchors", "zly_num_ops", "zly_op_info_at", "zly_op_kernel_name", "zly_profile_ops", "zly_get_stats",
 ]
 
 DET_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("w", "<f4"), ("h", "<f4"), ("confidence", "<f4"),
@@ -108,6 +108,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.zly_debug_tap.argtypes = [vp, C.c_char_p, i32, vp, sz, pi32, pi32, pi32]; lib.zly_debug_tap.restype = i32
     lib.zly_num_classes.argtypes = [vp]; lib.zly_num_classes.restype = i32
     lib.zly_num_anchors.argtypes = [vp]; lib.zly_num_anchors.restype = i32
+    lib.zly_weights_fp8.argtypes = [vp]; lib.zly_weights_fp8.restype = i32
     lib.zly_num_ops.argtypes = [vp]; lib.zly_num_ops.restype = i32
     lib.zly_op_info_at.argtypes = [vp, i32, C.POINTER(OpInfo)]; lib.zly_op_info_at.restype = i32
     lib.zly_op_kernel_name.argtypes = [vp, i32, i32, C.c_char_p, sz]; lib.zly_op_kernel_name.restype = i32
@@ -145,6 +146,7 @@ class Engine:
         self.h = h
         self.model_w, self.model_h, self.max_batch, self.max_dets = model_w, model_h, max_batch, max_dets
         self.nc = self.lib.zly_num_classes(h)
+        self.weights_fp8 = bool(self.lib.zly_weights_fp8(h))
         self.N = self.lib.zly_num_anchors(h)
         self.slab_bytes = int(self.lib.zly_slab_bytes(h))
 
