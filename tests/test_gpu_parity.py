@@ -621,7 +621,7 @@ def test_yolov8s_640_fp8_weights(tmp_path, oracle):
     want32 = ref32.forward(torch.from_numpy(x)).numpy()
     want16 = ref16.forward(torch.from_numpy(x)).numpy()
     assert want32.shape == (2, 84, 8400)
-    e = zly.Engine(p, model_w=640, model_h=640, max_batch=2, max_dets=1024, conf_thr=0.9, warmup_runs=0, flags=zly.FLAG_DUMP_LOGITS)
+    e = zly.Engine(p, model_w=640, model_h=640, max_batch=2, max_dets=1024, conf_thr=0.5, warmup_runs=0, flags=zly.FLAG_DUMP_LOGITS)
     assert e.weights_fp8
     got = e.forward(x)
     _assert_bf16_close(got, want16)
@@ -629,7 +629,7 @@ def test_yolov8s_640_fp8_weights(tmp_path, oracle):
     assert len(_check_taps(e, ref16, (0, 1), skip_ok=(".m.0.cv1", ".m.1.cv1"))) >= 55
     for i, f in enumerate(frames):
         dets, n = e.detect(f, cap=1024)
-        own = oracle.postprocess(e.head_tensor(0), 640, 640, 0.9, 0.45)
+        own = oracle.postprocess(e.head_tensor(0), 640, 640, 0.5, 0.45)
         assert n == len(own) and det_fields_equal(dets, own[:1024])
     e.close()
     e = zly.Engine(zly.DEFAULT_WEIGHTS, warmup_runs=0)

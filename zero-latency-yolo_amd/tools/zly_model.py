@@ -348,9 +348,75 @@ SYNTH_GAIN: Dict[str, float] = {
     "model.22.cv3.2.2": 5.9230,
 }
 
+SYNTH_GAIN_S: Dict[str, float] = {   # yolov8s (python oracle/calibrate_synth.py s)
+    "model.0": 0.9219,
+    "model.1": 1.9173,
+    "model.2.cv1": 1.9658,
+    "model.2.m.0.cv1": 1.8716,
+    "model.2.m.0.cv2": 1.9020,
+    "model.2.cv2": 1.6942,
+    "model.3": 1.9436,
+    "model.4.cv1": 1.8790,
+    "model.4.m.0.cv1": 1.9985,
+    "model.4.m.0.cv2": 1.8751,
+    "model.4.m.1.cv1": 1.4003,
+    "model.4.m.1.cv2": 2.0557,
+    "model.4.cv2": 1.4371,
+    "model.5": 2.0193,
+    "model.6.cv1": 1.9267,
+    "model.6.m.0.cv1": 1.9631,
+    "model.6.m.0.cv2": 1.9377,
+    "model.6.m.1.cv1": 1.3799,
+    "model.6.m.1.cv2": 2.0010,
+    "model.6.cv2": 1.4404,
+    "model.7": 1.9913,
+    "model.8.cv1": 1.9497,
+    "model.8.m.0.cv1": 1.9548,
+    "model.8.m.0.cv2": 1.9475,
+    "model.8.cv2": 1.6925,
+    "model.9.cv1": 1.9220,
+    "model.9.cv2": 1.3687,
+    "model.12.cv1": 1.9651,
+    "model.12.m.0.cv1": 1.8716,
+    "model.12.m.0.cv2": 1.7766,
+    "model.12.cv2": 1.9189,
+    "model.15.cv1": 1.9516,
+    "model.15.m.0.cv1": 2.0208,
+    "model.15.m.0.cv2": 2.1398,
+    "model.15.cv2": 2.0182,
+    "model.16": 1.8264,
+    "model.18.cv1": 1.9092,
+    "model.18.m.0.cv1": 1.8121,
+    "model.18.m.0.cv2": 1.8984,
+    "model.18.cv2": 1.9352,
+    "model.19": 1.9111,
+    "model.21.cv1": 1.9716,
+    "model.21.m.0.cv1": 1.8321,
+    "model.21.m.0.cv2": 2.0457,
+    "model.21.cv2": 1.9123,
+    "model.22.cv2.0.0": 1.9744,
+    "model.22.cv2.0.1": 1.7448,
+    "model.22.cv2.0.2": 2.7074,
+    "model.22.cv2.1.0": 2.0395,
+    "model.22.cv2.1.1": 1.9996,
+    "model.22.cv2.1.2": 2.9802,
+    "model.22.cv2.2.0": 2.2310,
+    "model.22.cv2.2.1": 2.0006,
+    "model.22.cv2.2.2": 4.7547,
+    "model.22.cv3.0.0": 2.0549,
+    "model.22.cv3.0.1": 1.9239,
+    "model.22.cv3.0.2": 5.3305,
+    "model.22.cv3.1.0": 1.9880,
+    "model.22.cv3.1.1": 2.0467,
+    "model.22.cv3.1.2": 5.9566,
+    "model.22.cv3.2.0": 2.0336,
+    "model.22.cv3.2.1": 1.9636,
+    "model.22.cv3.2.2": 5.4035,
+}
+
 
 def synth_weights(spec: ModelSpec, seed: int = SYNTH_SEED, gains: Dict[str, float] = None) -> Dict[str, Tuple[np.ndarray, np.ndarray]]:
-    gains = SYNTH_GAIN if gains is None else gains
+    gains = (SYNTH_GAIN_S if spec.scale == "s" else SYNTH_GAIN) if gains is None else gains
     rng = np.random.default_rng(seed)
     out = {}
     for c in spec.convs:
