@@ -380,7 +380,7 @@ def run():
                         f.write(f"{'TOTAL':44s} {'':4s} {float(ms.sum()):9.4f}\n\n")
             # HBM-side traffic of the same kernels from the PMC counters (collected off-line with rocprofv3, two
             # --pmc passes, gfx950 correction applied; see the file for provenance): per batch-64 step
-            tpath = os.path.join(ROOT, "profiles", "r01_traffic_b64.json")
+            tpath = os.path.join(ROOT, "profiles", "r02_traffic_b64.json")
             if B == 64 and os.path.exists(tpath):
                 tj = json.load(open(tpath))
                 roof[B]["traffic"] = tj["traffic_bytes_per_step"]

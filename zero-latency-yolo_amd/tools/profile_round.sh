@@ -1,0 +1,28 @@
+#!/bin/bash
+# Collects the round's profile set on the GPU box into gpurun_out/prof_$1/ (copy what is to be judged into profiles/):
+#   kernel trace + stats of the default bench headline, per-position table, one-step timeline, PMC traffic (two passes), per-op events
+set -e
+tag=${1:-r02}
+out=gpurun_out/prof_$tag
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
+export ZLY_BENCH_NO_H2H=1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -- python3 bench.py --batch 64 --steps 40 --warmup 5 --no-extras --no-cpu-baseline > $out/kt_bench.json 2> $out/kt.err
+kt=$(find $out/kt -name "*kernel_trace.csv" | head -1)
+st=$(find $out/kt -name "*kernel_stats.csv" | head -1)
+cp "$st" $out/kernel_stats.csv
+n=$(python3 - "$kt" <<'PY'
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+idx = [i for i, r in enumerate(rows) if "stem_model1_kernel" in r["Kernel_Name"] or "stem_fused_kernel" in r["Kernel_Name"]]
+print(idx[-2] - idx[-3])
+PY
+)
+python3 zero-latency-yolo_amd/tools/trace_summary.py "$kt" $n $out/per_position.txt
+python3 zero-latency-yolo_amd/tools/trace_timeline.py "$kt" 3 > $out/timeline.txt
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_r -- python3 bench.py --batch 64 --steps 6 --warmup 1 --no-extras --no-cpu-baseline > /dev/null 2> $out/pmc_r.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_w -- python3 bench.py --batch 64 --steps 6 --warmup 1 --no-extras --no-cpu-baseline > /dev/null 2> $out/pmc_w.err
+python3 zero-latency-yolo_amd/tools/pmc_traffic.py $out/pmc_r $out/pmc_w $out/traffic_b64.json
+rm -rf $out/pmc_r $out/pmc_w $out/kt
+echo "profile set in $out"

@@ -9,14 +9,14 @@ path, kps = sys.argv[1], int(sys.argv[2])
 rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # align on the preprocess kernel (first kernel of a step)
-starts = [i for i, r in enumerate(rows) if "preprocess_kernel" in r["Kernel_Name"] or "stem_fused_kernel" in r["Kernel_Name"]]
+starts = [i for i, r in enumerate(rows) if any(k in r["Kernel_Name"] for k in ("preprocess_kernel", "stem_fused_kernel", "stem_model1_kernel"))]
 starts = [i for i in starts if i + kps <= len(rows)]
 starts = starts[len(starts) // 3:]
 pos = collections.defaultdict(lambda: [0, 0.0, 0.0, "", ""])
 nsteps = 0
 for s in starts:
     step = rows[s:s + kps]
-    if sum(("preprocess_kernel" in r["Kernel_Name"] or "stem_fused_kernel" in r["Kernel_Name"]) for r in step) != 1:
+    if sum((any(k in r["Kernel_Name"] for k in ("preprocess_kernel", "stem_fused_kernel", "stem_model1_kernel"))) for r in step) != 1:
         continue
     nsteps += 1
     prev_end = None

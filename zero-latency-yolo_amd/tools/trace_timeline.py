@@ -6,7 +6,7 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 back = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-starts = [i for i, r in enumerate(rows) if "stem_fused_kernel" in r["Kernel_Name"] or "preprocess_kernel" in r["Kernel_Name"]]
+starts = [i for i, r in enumerate(rows) if any(k in r["Kernel_Name"] for k in ("preprocess_kernel", "stem_fused_kernel", "stem_model1_kernel"))]
 i0, i1 = starts[-back - 1], starts[-back]
 t0 = int(rows[i0]["Start_Timestamp"])
 step = rows[i0:i1 + 3]
