@@ -268,7 +268,7 @@ __global__ __launch_bounds__(NW * 64) void bottleneck_pair_kernel(const PairArgs
 // order.  Halo pixels of cv1 are recomputed by neighbouring tiles (1.3-1.7x the cv1 work; these layers are bound by bytes
 // and SiLU issue, not by MFMAs).  With a.dump (debug taps) the intermediates are also written to the concat buffer.
 // ------------------------------------------------------------------------------------------------
-template <int C, int MODE, int NW, int NLD>
+template <int C, int MODE, int NW, int NLD, int NK1>
 __global__ __launch_bounds__(NW * 64) void c2f_kernel(const C2fArgs a)
 {
     typedef PairGeom<C> G;
@@ -395,29 +395,44 @@ __global__ __launch_bounds__(NW * 64) void c2f_kernel(const C2fArgs a)
             const bf16_t* __restrict__ xb = static_cast<const bf16_t*>(a.x2) + a.x2_co;
             const bool dual = a.x2 != nullptr;
             const unsigned char* w1l = lw1 + lane * 16;
-            for (int t = wave; t < nt0; t += NW) {
-                const int q = t * 16 + p;
-                const int qc = min(q, NP0 - 1);
+            // the NK1 input fragments of a 16-pixel tile are loaded together, one tile ahead of the MFMAs that consume them: with one
+            // load per k-step every k-step exposed an L2 round trip (model.15.cv1: 6 per tile, most of the kernel's time)
+            auto load_x = [&](int t, bf16x8 (&xf)[NK1]) {
+                const int qc = min(t * 16 + p, NP0 - 1);
                 const int py = div_small(qc, invPW), px = qc - py * PW;
                 const int gy = y0 - 2 + py, gx = x0 - 2 + px;
                 const bool inimg = (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
                 const size_t pa = dual ? ((size_t)(b * (a.H >> 1) + (gy >> 1)) * (a.W >> 1) + (gx >> 1)) * a.x_cs : ((size_t)(b * a.H + gy) * a.W + gx) * a.x_cs;
                 const size_t pb2 = ((size_t)(b * a.H + gy) * a.W + gx) * a.x2_cs;
+#pragma unroll
+                for (int s = 0; s < NK1; ++s) {
+                    const int ci = s * 32 + kq * 8;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) xf[s][j] = (bf16_t)0.0f;
+                    if (inimg) xf[s] = (dual && ci >= a.split_c) ? *reinterpret_cast<const bf16x8*>(xb + pb2 + (ci - a.split_c)) : *reinterpret_cast<const bf16x8*>(xa + pa + ci);
+                }
+            };
+            bf16x8 xcur[NK1], xnext[NK1];
+            if (wave < nt0) load_x(wave, xcur);
+            for (int t = wave; t < nt0; t += NW) {
+                if (t + NW < nt0) load_x(t + NW, xnext);
+                const int q = t * 16 + p;
+                const int qc = min(q, NP0 - 1);
+                const int py = div_small(qc, invPW), px = qc - py * PW;
+                const int gy = y0 - 2 + py, gx = x0 - 2 + px;
+                const bool inimg = (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
                 f32x4 acc[T1];
 #pragma unroll
                 for (int c = 0; c < T1; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-                for (int s = 0; s < a.nk1; ++s) {
-                    const int ci = s * 32 + kq * 8;
-                    bf16x8 xf;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) xf[j] = (bf16_t)0.0f;
-                    if (inimg) xf = (dual && ci >= a.split_c) ? *reinterpret_cast<const bf16x8*>(xb + pb2 + (ci - a.split_c)) : *reinterpret_cast<const bf16x8*>(xa + pa + ci);
+                for (int s = 0; s < NK1; ++s)
 #pragma unroll
                     for (int c = 0; c < T1; ++c) {
-                        const bf16x8 wf = *reinterpret_cast<const bf16x8*>(w1l + (c * a.nk1 + s) * 1024);
-                        acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, acc[c], 0, 0, 0);
+                        const bf16x8 wf = *reinterpret_cast<const bf16x8*>(w1l + (c * NK1 + s) * 1024);
+                        acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xcur[s], acc[c], 0, 0, 0);
                     }
-                }
+#pragma unroll
+                for (int s = 0; s < NK1; ++s) xcur[s] = xnext[s];
                 f32x4 o[T1];
 #pragma unroll
                 for (int c = 0; c < T1; ++c) {
@@ -496,7 +511,6 @@ __global__ __launch_bounds__(NW * 64) void c2f_kernel(const C2fArgs a)
             __syncthreads();                           // y map complete
             // ---- cv2 over the concat [from HBM: channels below the bottleneck's input | patch interior | y] -> out -----------
             // k-step size = C (one source map per k-step); MODE 3: y0 comes from its LDS map instead of HBM
-            const int nglob = MODE == 2 ? a.pair_in_co / C : 0;
             const unsigned char* w2l = lw2 + lane * G::FRAGB;
             for (int t = wave; t < ntB; t += NW) {
                 const int q = t * 16 + p;
@@ -504,36 +518,25 @@ __global__ __launch_bounds__(NW * 64) void c2f_kernel(const C2fArgs a)
                 const int oy = div_small(qc, invTW), ox = qc - oy * a.TW;
                 const int gy = min(y0 + oy, a.H - 1), gx = min(x0 + ox, a.W - 1);
                 const bf16_t* gp = cat + ((size_t)(b * a.H + gy) * a.W + gx) * a.cat_cs + kq * (G::FRAGB / 2);
+                // the k-steps' fragments, in concat order, are all fetched before the MFMAs (MODE 2: the first two from HBM)
+                constexpr int NS = MODE == 2 ? 4 : 3;
+                F xs[NS];
+                if (MODE == 2) {
+                    xs[0] = *reinterpret_cast<const F*>(gp);
+                    xs[1] = *reinterpret_cast<const F*>(gp + C);
+                } else {
+                    xs[0] = *reinterpret_cast<const F*>(ly0 + (size_t)qc * G::PITCH + kq * G::FRAGB);
+                }
+                xs[NS - 2] = *reinterpret_cast<const F*>(lin + (size_t)((oy + 2) * PW + ox + 2) * G::PITCH + kq * G::FRAGB);
+                xs[NS - 1] = *reinterpret_cast<const F*>(ly2 + (size_t)qc * G::PITCH + kq * G::FRAGB);
                 f32x4 acc[T2MAX];
 #pragma unroll
                 for (int c = 0; c < T2MAX; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-                int s = 0;
-                for (; s < nglob; ++s) {
-                    const F xf = *reinterpret_cast<const F*>(gp + s * C);
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
 #pragma unroll
                     for (int c = 0; c < T2MAX; ++c)
-                        if (c < T2) acc[c] = G::mma(*reinterpret_cast<const F*>(w2l + (c * a.nk2 + s) * G::WTILE), xf, acc[c]);
-                }
-                if (MODE == 3) {
-                    const F xf = *reinterpret_cast<const F*>(ly0 + (size_t)qc * G::PITCH + kq * G::FRAGB);
-#pragma unroll
-                    for (int c = 0; c < T2MAX; ++c)
-                        if (c < T2) acc[c] = G::mma(*reinterpret_cast<const F*>(w2l + (c * a.nk2 + s) * G::WTILE), xf, acc[c]);
-                    ++s;
-                }
-                {
-                    const F xf = *reinterpret_cast<const F*>(lin + (size_t)((oy + 2) * PW + ox + 2) * G::PITCH + kq * G::FRAGB);
-#pragma unroll
-                    for (int c = 0; c < T2MAX; ++c)
-                        if (c < T2) acc[c] = G::mma(*reinterpret_cast<const F*>(w2l + (c * a.nk2 + s) * G::WTILE), xf, acc[c]);
-                    ++s;
-                }
-                {
-                    const F xf = *reinterpret_cast<const F*>(ly2 + (size_t)qc * G::PITCH + kq * G::FRAGB);
-#pragma unroll
-                    for (int c = 0; c < T2MAX; ++c)
-                        if (c < T2) acc[c] = G::mma(*reinterpret_cast<const F*>(w2l + (c * a.nk2 + s) * G::WTILE), xf, acc[c]);
-                }
+                        if (c < T2) acc[c] = G::mma(*reinterpret_cast<const F*>(w2l + (c * NS + s) * G::WTILE), xs[s], acc[c]);
                 if (q < NPB && y0 + oy < a.H && x0 + ox < a.W) {
                     bf16_t* dst = static_cast<bf16_t*>(a.out) + ((size_t)(b * a.H + gy) * a.W + gx) * a.out_cs + a.out_co;
 #pragma unroll
@@ -621,10 +624,14 @@ static size_t c2f_lds_bytes(int c, int mode, int nk1, int nk2, int cout2, int th
     return b;
 }
 
+typedef void (*c2f_fn)(const C2fArgs);
+static c2f_fn pick_c2f(int c, int mode, int nk1);
+
 // tile shape: rounds of tiles over the CUs x (16-pixel tile rounds of the phases over the workgroup's waves + a fixed cost), LDS budget
 bool c2f_plan(int c, int mode, int nk1, int nk2, int cout2, int n, int H, int W, C2fPlan* plan)
 {
-    if ((c != 16 && c != 32) || mode < 1 || mode > 3) return false;
+    if ((c != 16 && c != 32) || mode < 1 || mode > 3 || !pick_c2f(c, mode, nk1)) return false;
+    if ((mode & 2) && nk2 != (mode == 2 ? 4 : 3)) return false;          // concat of 3 (one bottleneck) or 4 (back half of two) sources
     const int ncu = num_cus(), nw = c == 16 ? C2F_NW16 : C2F_NW32;
     double best = 1e30;
     for (int th = 4; th <= 32; ++th) {
@@ -652,20 +659,28 @@ bool c2f_plan(int c, int mode, int nk1, int nk2, int cout2, int n, int H, int W,
     return true;
 }
 
-typedef void (*c2f_fn)(const C2fArgs);
-static c2f_fn pick_c2f(int c, int mode)
+// variants built: cv1 with 1, 2 or 6 k-steps of 32 input channels (YOLOv8n: model.2 32 ch, model.4 64 ch, model.15 192 ch); the back half
+// (mode 2) has no cv1
+template <int C, int NW> static c2f_fn pick_c2f_c(int mode, int nk1)
 {
-    if (c == 16) return mode == 1 ? c2f_kernel<16, 1, C2F_NW16, C2F_NLD> : mode == 2 ? c2f_kernel<16, 2, C2F_NW16, C2F_NLD> : c2f_kernel<16, 3, C2F_NW16, C2F_NLD>;
-    return mode == 1 ? c2f_kernel<32, 1, C2F_NW32, C2F_NLD> : mode == 2 ? c2f_kernel<32, 2, C2F_NW32, C2F_NLD> : c2f_kernel<32, 3, C2F_NW32, C2F_NLD>;
+    if (mode == 2) return c2f_kernel<C, 2, NW, C2F_NLD, 1>;
+    if (mode == 1) return nk1 == 1 ? c2f_kernel<C, 1, NW, C2F_NLD, 1> : nk1 == 2 ? c2f_kernel<C, 1, NW, C2F_NLD, 2> : nk1 == 6 ? c2f_kernel<C, 1, NW, C2F_NLD, 6> : nullptr;
+    return nk1 == 1 ? c2f_kernel<C, 3, NW, C2F_NLD, 1> : nk1 == 2 ? c2f_kernel<C, 3, NW, C2F_NLD, 2> : nk1 == 6 ? c2f_kernel<C, 3, NW, C2F_NLD, 6> : nullptr;
+}
+static c2f_fn pick_c2f(int c, int mode, int nk1)
+{
+    return c == 16 ? pick_c2f_c<16, C2F_NW16>(mode, nk1) : pick_c2f_c<32, C2F_NW32>(mode, nk1);
 }
 
 hipError_t c2f_init()
 {
+    static const int nk1s[3] = {1, 2, 6};
     for (int c = 16; c <= 32; c += 16)
-        for (int mode = 1; mode <= 3; ++mode) {
-            hipError_t r = hipFuncSetAttribute((const void*)pick_c2f(c, mode), hipFuncAttributeMaxDynamicSharedMemorySize, PAIR_LDS_MAX);
-            if (r != hipSuccess) return r;
-        }
+        for (int mode = 1; mode <= 3; ++mode)
+            for (int i = 0; i < 3; ++i) {
+                hipError_t r = hipFuncSetAttribute((const void*)pick_c2f(c, mode, nk1s[i]), hipFuncAttributeMaxDynamicSharedMemorySize, PAIR_LDS_MAX);
+                if (r != hipSuccess) return r;
+            }
     return hipSuccess;
 }
 
@@ -676,7 +691,9 @@ hipError_t launch_c2f(int c, int mode, const C2fArgs& a, const C2fPlan& plan, hi
     if ((mode & 1) && (a.x_cs % 8 || a.x_co % 8 || (a.x2 && (a.x2_cs % 8 || a.x2_co % 8 || a.split_c % 32 || (a.H & 1) || (a.W & 1))))) return hipErrorInvalidValue;
     if ((mode & 2) && (a.Cout2 % 32 || a.Cout2 > 64)) return hipErrorInvalidValue;
     const int nw = c == 16 ? C2F_NW16 : C2F_NW32;
-    hipLaunchKernelGGL(pick_c2f(c, mode), dim3((unsigned)plan.grid), dim3(nw * 64), (size_t)plan.lds_bytes, s, a);
+    c2f_fn fn = pick_c2f(c, mode, a.nk1);
+    if (!fn || (mode == 2 && a.pair_in_co != 2 * c)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(fn, dim3((unsigned)plan.grid), dim3(nw * 64), (size_t)plan.lds_bytes, s, a);
     return hipGetLastError();
 }
 
