@@ -66,6 +66,9 @@ extern "C" {
 #define ZLY_FLAG_ASYNC_NMS   8   /* zly_detect_device only: NMS of a call runs on an engine-owned stream beside the first kernels of the
                                    NEXT call (it is 64 latency-bound workgroups).  The slabs of a call are then complete after zly_join
                                    (stream order) or zly_sync / zly_read_slabs (host), whichever comes first. */
+#define ZLY_FLAG_SINGLE_CHAIN 16 /* no side streams: the whole step is one chain of launches on one stream.  For SEVERAL engines per GPU fed alternate
+                                   batches (their chains overlap each other: the idle time at every kernel boundary of one is filled by the other);
+                                   needs one hardware queue per stream, i.e. GPU_MAX_HW_QUEUES=8 in the environment before HIP starts */
 #define ZLY_FLAG_NO_FUSION   2   /* run every conv as its own kernel (no fused bottleneck pairs): every zly_debug_tap is then available */
 
 typedef struct zly_engine zly_engine;

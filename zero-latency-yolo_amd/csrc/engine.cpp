@@ -582,8 +582,10 @@ static int build_plan(zly_engine* e, std::string* err)
 // ------------------------------------------------------------------------------------------------
 // Detect branches on side streams (and per-level tail launches): measured at batch 1 the cross-stream edges cost more
 // than the overlap buys (0.27 -> 0.34 ms/frame); from batch 16 up the branches are long enough to pay
+static bool g_single_chain = false;      // set by zly_create for ZLY_FLAG_SINGLE_CHAIN engines (process-wide: engines of one process share the choice)
 static bool lanes_active(int n)
 {
+    if (g_single_chain) return false;
     static const bool no_lanes = getenv("ZLY_NO_LANES") != nullptr || getenv("ZLY_CU_PART") != nullptr;     // tuning aid; a CU partition runs one chain
     return n >= 16 && !no_lanes;
 }
@@ -1334,6 +1336,7 @@ int32_t zly_create(const zly_config* cfg, zly_engine** out)
     HIP_TRY(stem1_init(), ZLY_ERR_SYSTEM);
     HIP_TRY(c2f_init(), ZLY_ERR_SYSTEM);
 
+    if (cfg->flags & ZLY_FLAG_SINGLE_CHAIN) g_single_chain = true;
     zly_engine* e = new zly_engine();
     e->cfg = *cfg;
     e->weights_path = cfg->weights_path ? cfg->weights_path : "";
@@ -1362,7 +1365,10 @@ int32_t zly_create(const zly_config* cfg, zly_engine** out)
         return hipStreamCreateWithFlags(st, hipStreamNonBlocking) == hipSuccess;
     };
     bool sok = make_stream(&e->stream);
-    for (int i = 0; i < 2 && sok; ++i) {
+    // side streams only when the Detect-branch lanes can be used: every stream beyond the hardware-queue limit (GPU_MAX_HW_QUEUES) shares
+    // a hardware queue with another one, and two streams on one queue serialise -- several engines per GPU want few streams each
+    const bool want_lanes = !(cfg->flags & ZLY_FLAG_SINGLE_CHAIN) && getenv("ZLY_NO_LANES") == nullptr && getenv("ZLY_CU_PART") == nullptr;
+    for (int i = 0; i < 2 && sok && want_lanes; ++i) {
         sok = make_stream(&e->side[i]) &&
               hipEventCreateWithFlags(&e->ev_fork[i], hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming) == hipSuccess;

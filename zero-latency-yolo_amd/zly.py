@@ -30,6 +30,7 @@ FLAG_DUMP_LOGITS = 1
 FLAG_NO_FUSION = 2
 FLAG_NO_HEAD_TENSOR = 4
 FLAG_ASYNC_NMS = 8
+FLAG_SINGLE_CHAIN = 16
 
 # every symbol include/zly.h declares (tests/test_abi.py checks the library exports them all)
 SYMBOLS = [
