@@ -89,41 +89,50 @@ def host_cores():
 FORCE_GATHER = os.environ.get("ZLY_BENCH_FORCE_GATHER") == "1"
 
 
-def run_steps(eng, frame_sets, batch, steps, slabs, stream_ptr, world, gather_out, size=416):
-    """enqueue `steps` steps.  The engine runs NMS of step k on its own stream beside the first kernels of step k+1
-    (ZLY_FLAG_ASYNC_NMS); with world > 1 the slabs of step k are all-gathered once step k+1 has been enqueued:
-    zly_join orders the stream behind NMS(k), then the collective is queued -- overlapped with step k+1."""
+def run_steps(engs, frame_sets, batch, steps, slabs, stream_ptr, world, gather_out, size=416):
+    """enqueue `steps` steps, step k on engine k % len(engs).
+    One engine: it enqueues on the caller's stream and runs NMS of step k on its own stream beside the first kernels of step k+1
+    (ZLY_FLAG_ASYNC_NMS).  Several engines (ZLY_FLAG_SINGLE_CHAIN): each step is one chain of launches on its engine's own stream and
+    the chains of consecutive steps overlap -- what one chain leaves idle at its ~50 kernel boundaries and in its latency-bound small-map
+    layers, the others fill.  With world > 1 the slabs of step k are all-gathered once step k+1 has been enqueued: zly_join orders the
+    caller's stream behind step k's NMS, then the collective is queued -- overlapped with the following steps."""
     import torch.distributed as dist
-    works = []
+    n_eng = len(engs)
+    ring = len(slabs)
+    works = {}
     gather = world > 1 or FORCE_GATHER
 
     def gather_step(j, lag):
-        eng.join(stream_ptr, lag)
-        if len(works) >= 2:
-            works.pop(0).wait()                        # gather buffer j%2 is free again once its previous gather finished
-        works.append(dist.all_gather_into_tensor(gather_out[j % 2], slabs[j % 3], async_op=True))
+        engs[j % n_eng].join(stream_ptr, lag)
+        if j - 2 in works:
+            works.pop(j - 2).wait()                    # gather buffer j%2 is free again once its previous gather finished
+        works[j] = dist.all_gather_into_tensor(gather_out[j % 2], slabs[j % ring], async_op=True)
 
     for k in range(steps):
         d = frame_sets[k % len(frame_sets)]
-        eng.detect_device(d.data_ptr(), batch, size, size, d_slabs_ptr=slabs[k % 3].data_ptr(), tag0=k * batch, stream=stream_ptr)
+        if k - ring in works:
+            works.pop(k - ring).wait()                 # the slab buffer of step k - ring has been gathered
+        engs[k % n_eng].detect_device(d.data_ptr(), batch, size, size, d_slabs_ptr=slabs[k % ring].data_ptr(), tag0=k * batch,
+                                      stream=stream_ptr if n_eng == 1 else 0)
         if gather and k > 0:
-            gather_step(k - 1, 1)                      # NMS(k-1), not NMS(k): step k+1 must not queue behind NMS(k)
+            gather_step(k - 1, 1 if n_eng == 1 else 0)     # one engine: NMS(k-1), not NMS(k) -- step k+1 must not queue behind NMS(k)
     if gather and steps > 0:
         gather_step(steps - 1, 0)
-    for w in works:
+    for w in works.values():
         w.wait()
-    eng.join(stream_ptr)                               # the last NMS is ordered into the timed stream
+    for e in engs:
+        e.join(stream_ptr)                             # every engine's last NMS is ordered into the timed stream
 
 
-def timed(eng, frame_sets, batch, steps, warmup, slabs, stream_ptr, world, gather_out, size=416):
+def timed(engs, frame_sets, batch, steps, warmup, slabs, stream_ptr, world, gather_out, size=416):
     import torch.distributed as dist
-    run_steps(eng, frame_sets, batch, warmup, slabs, stream_ptr, world, gather_out, size)
+    run_steps(engs, frame_sets, batch, warmup, slabs, stream_ptr, world, gather_out, size)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    run_steps(eng, frame_sets, batch, steps, slabs, stream_ptr, world, gather_out, size)
+    run_steps(engs, frame_sets, batch, steps, slabs, stream_ptr, world, gather_out, size)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -227,6 +236,8 @@ def run():
     ap.add_argument("--size", type=int, default=416, help="square model/frame size; 640 = BASELINE configs[3] (then only the headline leg runs)")
     ap.add_argument("--scale", default="n", choices=["n", "s"], help="model scale; s + --fp8 + --size 640 = BASELINE configs[4] per GPU (then only the headline leg runs)")
     ap.add_argument("--fp8", action="store_true", help="weights stored as fp8 e4m3 (dequantised at load; the engine computes in bf16)")
+    ap.add_argument("--engines", type=int, default=3, help="engine instances per GPU fed alternate steps (ZLY_FLAG_SINGLE_CHAIN when > 1); 1 = one engine with "
+                                                          "side streams + deferred NMS")
     ap.add_argument("--sync-nms", action="store_true", help="run NMS in stream order at the end of every step instead of beside the next step's first kernels")
     ap.add_argument("--dump-ops", default="", help="write the per-op hipEvent profile (name, ms, GFLOP, GB, TFLOP/s, GB/s) to this file")
     a = ap.parse_args()
@@ -260,8 +271,14 @@ def run():
             zm.write_zlyw(wpath, spec_, zm.synth_weights(spec_), fp8=a.fp8)
         if world > 1:
             dist.barrier()
-    eng = zly.Engine(wpath, dtype=zly.DTYPE_BF16, model_w=a.size, model_h=a.size, max_batch=max(B, big), max_dets=64, device=local_rank, warmup_runs=3,
-                     use_graph=not a.eager, flags=(0 if a.keep_head else zly.FLAG_NO_HEAD_TENSOR) | (0 if a.sync_nms else zly.FLAG_ASYNC_NMS))
+    n_eng = max(1, a.engines)
+    if n_eng > 1:
+        eflags = (0 if a.keep_head else zly.FLAG_NO_HEAD_TENSOR) | zly.FLAG_SINGLE_CHAIN      # NMS in chain order: the other engines fill its tail
+    else:
+        eflags = (0 if a.keep_head else zly.FLAG_NO_HEAD_TENSOR) | (0 if a.sync_nms else zly.FLAG_ASYNC_NMS)
+    engs = [zly.Engine(wpath, dtype=zly.DTYPE_BF16, model_w=a.size, model_h=a.size, max_batch=max(B, big), max_dets=64, device=local_rank, warmup_runs=3,
+                       use_graph=not a.eager, flags=eflags) for _ in range(n_eng)]
+    eng = engs[0]
     # a real (non-default) torch stream: the engine enqueues on it, and torch.distributed orders the RCCL
     # all-gather of the slabs behind it (with the legacy default stream the engine would fall back to its
     # own stream and the collective would not be ordered after NMS)
@@ -276,7 +293,7 @@ def run():
     sb = eng.slab_bytes
 
     def slab_bufs(n):
-        return [torch.zeros(n * sb, dtype=torch.uint8, device="cuda") for _ in range(3)]   # step k's slabs are gathered while k+1 runs and k+2 is enqueued
+        return [torch.zeros(n * sb, dtype=torch.uint8, device="cuda") for _ in range(n_eng + 3)]   # step k's slabs are gathered while the next steps run / are enqueued
 
     def gather_bufs(n):
         return [torch.zeros(world * n * sb, dtype=torch.uint8, device="cuda") for _ in range(2)] if (world > 1 or force_gather) else None
@@ -284,7 +301,7 @@ def run():
     log(f"engine ready (rank {rank}/{world}), headline leg: batch {B} x {a.steps} steps")
     # ---- headline: BASELINE config[1] (batch B per GPU per step) -----------------------------------
     gb_head = gather_bufs(B)
-    dt = timed(eng, sets_b, B, a.steps, a.warmup, slab_bufs(B), sp, world, gb_head, a.size)
+    dt = timed(engs, sets_b, B, a.steps, a.warmup, slab_bufs(B), sp, world, gb_head, a.size)
     value = world * B * a.steps / dt
     ms_per_step = dt / a.steps * 1e3
     result = {
@@ -292,7 +309,9 @@ def run():
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 5),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"YOLOv8-{'nano' if a.scale == 'n' else 'small'} {a.size}x{a.size} batch={B} streaming throughput path, bf16{' (fp8 e4m3 weight file)' if a.fp8 else ''}, per MI355X, frames resident in HBM, "
-                               f"preprocess+forward+decode+NMS per step" + (", slabs all-gathered over RCCL" if world > 1 else ""),
+                               f"preprocess+forward+decode+NMS per step" + (f", steps alternate over {n_eng} engine instances whose chains overlap" if n_eng > 1 else "") +
+                               (", slabs all-gathered over RCCL" if world > 1 else ""),
+                   "engines_per_gpu": n_eng,
                    "frames_per_step_per_gpu": B, "global_frames_per_step": world * B, "conf": 0.5, "iou": 0.45,
                    "weights": "seeded synthetic (no real weights offline)", "graph": not a.eager,
                    "parallelism": f"frame-sharded x{world}" if world > 1 else "single GPU"},
@@ -301,7 +320,7 @@ def run():
         # ---- BASELINE configs[1]: batch 1, the latency path, frames resident in HBM ---------------------
         k1 = max(200, a.steps * 2)
         log(f"headline {value:.0f} frames/s; batch-1 leg")
-        dt1 = timed(eng, sets_1, 1, k1, max(20, a.warmup), slab_bufs(1), sp, world, gather_bufs(1))
+        dt1 = timed(engs[:1], sets_1, 1, k1, max(20, a.warmup), slab_bufs(1), sp, world, gather_bufs(1))      # the latency path: ONE in-order chain
         result["latency_path_b1"] = {"value": round(world * k1 / dt1, 1), "unit": "frames/s", "steps": k1,
                                      "ms_per_step": round(dt1 / k1 * 1e3, 5), "frames_per_step_per_gpu": 1}
         if rank == 0:
@@ -385,6 +404,9 @@ def run():
                 tj = json.load(open(tpath))
                 roof[B]["traffic"] = tj["traffic_bytes_per_step"]
                 roof[B]["traffic_note"] = "bytes per step from " + os.path.relpath(tpath, ROOT) + ": " + tj["correction"]
+            roof[B]["whole_step"] = {"note": "algorithmic conv flops of a step / wall time per step (overlapping chains included)",
+                                     "achieved": round(roof[B]["algorithmic_gflop_per_step"] / ms_per_step, 1), "unit": "TFLOP/s",
+                                     "frac": round(roof[B]["algorithmic_gflop_per_step"] / ms_per_step / PEAK_BF16_TFLOPS, 4)}
             result["roofline"] = roof[B]
             if B != 1:
                 result["roofline_b1"] = roof[1]
@@ -410,7 +432,8 @@ def run():
         assert (hd[:, 0] >= 0).all() and (hd[:, 1] >= hd[:, 0]).all(), "malformed gathered slabs"
         result["gather"] = {"ranks": world, "bytes_per_rank_per_step": B * sb, "frames_checked": int(hd.shape[0])}
         dist.barrier()
-    eng.close()
+    for e_ in engs:
+        e_.close()
     if world > 1 or force_gather:
         dist.destroy_process_group()
     return json.dumps(result) if rank == 0 else None

@@ -264,8 +264,8 @@ def test_fused_stem_kernels_vs_oracle(eng16d, weights_path, oracle, ref_bf16, mo
         e.close()
 
 
-@pytest.mark.parametrize("n", [16, 64])
-def test_production_kernels_layerwise_vs_oracle(weights_path, oracle, ref_fp32, ref_bf16, n):
+@pytest.mark.parametrize("n,chain", [(16, "lanes"), (64, "lanes"), (64, "single")])
+def test_production_kernels_layerwise_vs_oracle(weights_path, oracle, ref_fp32, ref_bf16, n, chain):
     """The kernels the headline number runs, at the batch sizes that select them (conv3x3_lds_kernel S = 1 / 2, resident and
     per-item weights; conv1x1_stream_kernel in every (CT, PT, NK) shape; bottleneck_pair_kernel; stem_fused_kernel; the
     dual-source 1x1 convs; Detect branches on the side streams with per-level tail launches; deferred NMS), checked at
@@ -278,7 +278,10 @@ def test_production_kernels_layerwise_vs_oracle(weights_path, oracle, ref_fp32, 
     x = torch.from_numpy(_pre(oracle, frames))
     want16 = ref_bf16.forward(x).numpy()
     want32 = ref_fp32.forward(x).numpy()
-    e = zly.Engine(weights_path, max_batch=n, max_dets=128, warmup_runs=1, flags=zly.FLAG_ASYNC_NMS | zly.FLAG_DUMP_LOGITS)
+    # "lanes": one engine, Detect branches on side streams, deferred NMS; "single": ZLY_FLAG_SINGLE_CHAIN, the configuration several
+    # engines per GPU run (bench.py --engines 3): per-level tail launches in chain order, NMS in chain order
+    flags = (zly.FLAG_ASYNC_NMS if chain == "lanes" else zly.FLAG_SINGLE_CHAIN) | zly.FLAG_DUMP_LOGITS
+    e = zly.Engine(weights_path, max_batch=n, max_dets=128, warmup_runs=1, flags=flags)
     d = torch.from_numpy(frames).cuda()
     e.detect_device(d.data_ptr(), n, 416, 416)
     slabs = e.read_slabs(n)
@@ -698,6 +701,43 @@ def test_deferred_nms_same_slabs(weights_path):
     d2, n2 = a.detect(sets[2][3], cap=64)
     assert n1 == n2 and det_fields_equal(d1, d2)
     a.close(); b.close()
+
+
+def test_several_single_chain_engines_alternate(weights_path):
+    """bench.py's headline configuration: three ZLY_FLAG_SINGLE_CHAIN engines on one GPU, steps alternate between them, each on its
+    engine's own stream (the chains overlap), zly_join orders a foreign stream behind a step's NMS before its slabs are consumed.
+    Every step's slabs must be the bytes one engine produces for the same frames on its own."""
+    n, steps = 16, 9
+    sets = [torch.from_numpy(zm.synth_frames(n, 416, 416, seed=80 + i, rects=False)).cuda() for i in range(3)]
+    one = zly.Engine(weights_path, max_batch=n, max_dets=64, warmup_runs=1, flags=zly.FLAG_SINGLE_CHAIN)
+    want = []
+    for k in range(steps):
+        one.detect_device(sets[k % 3].data_ptr(), n, 416, 416, tag0=1000 * k)
+        want.append(one.read_slabs(n))
+    one.close()
+    engs = [zly.Engine(weights_path, max_batch=n, max_dets=64, warmup_runs=1, flags=zly.FLAG_SINGLE_CHAIN | zly.FLAG_NO_HEAD_TENSOR) for _ in range(3)]
+    sb = engs[0].slab_bytes
+    bufs = [torch.zeros(n * sb, dtype=torch.uint8, device="cuda") for _ in range(steps)]
+    host = [torch.zeros(n * sb, dtype=torch.uint8).pin_memory() for _ in range(steps)]
+    consumer = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for k in range(steps):
+        e = engs[k % 3]
+        e.detect_device(sets[k % 3].data_ptr(), n, 416, 416, d_slabs_ptr=bufs[k].data_ptr(), tag0=1000 * k)     # the engine's own stream
+        e.join(consumer.cuda_stream, 0)                                                                         # consumer waits for step k only
+        with torch.cuda.stream(consumer):
+            host[k].copy_(bufs[k], non_blocking=True)
+    consumer.synchronize()
+    total = 0
+    for k in range(steps):
+        got = zly.parse_slabs(host[k].numpy(), n, 64)
+        for i in range(n):
+            assert int(got[i][0]["frame_tag"]) == 1000 * k + i and int(got[i][0]["n_kept"]) == int(want[k][i][0]["n_kept"])
+            assert det_fields_equal(got[i][1], want[k][i][1])
+            total += int(got[i][0]["n_kept"])
+    assert total > 0
+    for e in engs:
+        e.close()
 
 
 def test_streaming_1x1_kernel(weights_path, oracle, monkeypatch):

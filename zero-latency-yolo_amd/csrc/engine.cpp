@@ -158,6 +158,11 @@ struct zly_engine {
     int t_frames = 0;
     unsigned sample_ctr = 0;
 
+    // completion of the last two zly_detect_device calls (recorded behind each call's NMS, on whichever stream it ran): zly_join orders
+    // a foreign stream behind them -- the RCCL gather of a step's slabs when the step ran on the engine's own stream (several engines
+    // per GPU) or with deferred NMS
+    hipEvent_t ev_call[2] = {nullptr, nullptr};
+    uint64_t call_seq = 0;
     int cu_part_n = 1;                // ZLY_CU_PART: number of CU partitions (1 = whole chip)
     uint32_t cu_mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     std::atomic<Ingest*> ingest{nullptr};   // created by the first zly_submit (under mu), read lock-free afterwards
@@ -582,10 +587,9 @@ static int build_plan(zly_engine* e, std::string* err)
 // ------------------------------------------------------------------------------------------------
 // Detect branches on side streams (and per-level tail launches): measured at batch 1 the cross-stream edges cost more
 // than the overlap buys (0.27 -> 0.34 ms/frame); from batch 16 up the branches are long enough to pay
-static bool g_single_chain = false;      // set by zly_create for ZLY_FLAG_SINGLE_CHAIN engines (process-wide: engines of one process share the choice)
-static bool lanes_active(int n)
+static bool lanes_active(const zly_engine* e, int n)
 {
-    if (g_single_chain) return false;
+    if (e->cfg.flags & ZLY_FLAG_SINGLE_CHAIN) return false;
     static const bool no_lanes = getenv("ZLY_NO_LANES") != nullptr || getenv("ZLY_CU_PART") != nullptr;     // tuning aid; a CU partition runs one chain
     return n >= 16 && !no_lanes;
 }
@@ -638,7 +642,7 @@ static bool op_is_noop(zly_engine* e, const Op& op, int n)
     if (op.kind == OP_CONV && e->stem1 && op.name == "model.1") return true;     // detect paths: computed by stem_model1_kernel (booked on model.0)
     if (op.kind == OP_CONV && c2f_covered(e, op, n)) return true;
     if (op.kind == OP_CONV && op.pair == 2) return pair_active(e, op, n) != nullptr;
-    if (op.kind == OP_HEAD && op.level != 2) return !lanes_active(n) || getenv("ZLY_NO_TAIL_SPLIT") != nullptr;
+    if (op.kind == OP_HEAD && op.level != 2) return !lanes_active(e, n) || getenv("ZLY_NO_TAIL_SPLIT") != nullptr;
     return false;
 }
 
@@ -718,7 +722,7 @@ static hipError_t run_op(zly_engine* e, const Op& op, int n, const uint8_t* d_sr
     case OP_HEAD: {
         HeadArgs h = op.head;
         static const bool no_split = getenv("ZLY_NO_TAIL_SPLIT") != nullptr;   // tuning aid
-        if (lanes_active(n) && !no_split) h.only_level = op.level;       // per-level launches (+0.3 % at batch 64)
+        if (lanes_active(e, n) && !no_split) h.only_level = op.level;       // per-level launches (+0.3 % at batch 64)
         else if (op.level != 2) return hipSuccess;          // the last tail op covers all levels
         else h.only_level = -1;
         h.head = (e->cfg.flags & ZLY_FLAG_NO_HEAD_TENSOR) ? nullptr : e->d_head; h.desc = e->d_desc; h.conf_thr = e->cfg.conf_thr; h.cand = e->cur_cand; h.cand_count = e->cur_count;
@@ -750,7 +754,7 @@ static hipError_t run_ops(zly_engine* e, size_t first, size_t last, int n, const
         hipStream_t st = s;
         // measured: at batch 1 the cross-stream edges cost more than the overlap buys (0.27 -> 0.34 ms/frame);
         // from batch 16 up the Detect branches are long enough to pay (1.42 -> 1.38 ms per 64 frames)
-        if (op.lane > 0 && lanes_active(n)) {
+        if (op.lane > 0 && lanes_active(e, n)) {
             st = e->side[op.lane - 1];
             if (!forked[op.lane]) {
                 r = hipEventRecord(e->ev_fork[op.lane - 1], s);
@@ -963,6 +967,7 @@ static void destroy_engine(zly_engine* e)
     for (int i = 0; i < 2; ++i) if (e->ev_nms[i]) hipEventDestroy(e->ev_nms[i]);
     for (int i = 0; i < zly_engine::DESC_RING; ++i) if (e->ev_desc[i]) hipEventDestroy(e->ev_desc[i]);
     for (int i = 0; i < 4; ++i) if (e->ev_t[i]) hipEventDestroy(e->ev_t[i]);
+    for (int i = 0; i < 2; ++i) if (e->ev_call[i]) hipEventDestroy(e->ev_call[i]);
     if (e->nms_stream) hipStreamDestroy(e->nms_stream);
     if (e->stream) hipStreamDestroy(e->stream);
     delete e;
@@ -1336,7 +1341,6 @@ int32_t zly_create(const zly_config* cfg, zly_engine** out)
     HIP_TRY(stem1_init(), ZLY_ERR_SYSTEM);
     HIP_TRY(c2f_init(), ZLY_ERR_SYSTEM);
 
-    if (cfg->flags & ZLY_FLAG_SINGLE_CHAIN) g_single_chain = true;
     zly_engine* e = new zly_engine();
     e->cfg = *cfg;
     e->weights_path = cfg->weights_path ? cfg->weights_path : "";
@@ -1388,6 +1392,7 @@ int32_t zly_create(const zly_config* cfg, zly_engine** out)
     ok = ok && hipHostMalloc((void**)&e->h_desc, zly_engine::DESC_RING * B * sizeof(FrameDesc), hipHostMallocDefault) == hipSuccess;
     for (int i = 0; i < zly_engine::DESC_RING && ok; ++i) ok = hipEventCreateWithFlags(&e->ev_desc[i], hipEventDisableTiming) == hipSuccess;
     for (int i = 0; i < 4 && ok; ++i) ok = hipEventCreate(&e->ev_t[i]) == hipSuccess;
+    for (int i = 0; i < 2 && ok; ++i) ok = hipEventCreateWithFlags(&e->ev_call[i], hipEventDisableTiming) == hipSuccess;
     ok = ok && hipHostMalloc((void**)&e->h_slabs, B * slab_bytes_of(e), hipHostMallocDefault) == hipSuccess;
     if (!ok) { destroy_engine(e); return fail(ZLY_ERR_SYSTEM, "device allocation failed"); }
     hipMemset(e->d_slabs, 0, B * slab_bytes_of(e));
@@ -1525,8 +1530,11 @@ int32_t zly_detect_device(zly_engine* e, int32_t n, const void* d_frames, int32_
     for (int i = 0; i < n; ++i) offs[(size_t)i] = (size_t)i * (size_t)w * (size_t)h * 3u;
     int rc = set_desc(e, n, ws.data(), hs.data(), offs.data(), s);
     if (rc != ZLY_OK) return rc;
-    rc = run_path(e, n, (const uint8_t*)d_frames, d_slabs, frame_tag0, s, true, (e->cfg.flags & ZLY_FLAG_ASYNC_NMS) != 0);
+    hipStream_t ns = s;
+    rc = run_path(e, n, (const uint8_t*)d_frames, d_slabs, frame_tag0, s, true, (e->cfg.flags & ZLY_FLAG_ASYNC_NMS) != 0, &ns);
     if (rc != ZLY_OK) { with_stats(e, [](zly_stats& st) { st.inference_errors++; }); return rc; }
+    HIP_TRY(hipEventRecord(e->ev_call[e->call_seq & 1], ns), ZLY_ERR_INFERENCE);
+    e->call_seq++;
     with_stats(e, [&](zly_stats& st) { st.inference_count += (uint64_t)n; });
     return ZLY_OK;
 }
@@ -1537,7 +1545,11 @@ int32_t zly_join(zly_engine* e, void* stream, int32_t lag)
     if (lag < 0) return fail(ZLY_ERR_INVALID_ARGUMENT, "lag must be >= 0");
     std::lock_guard<std::mutex> lk(e->mu);
     HIP_TRY(hipSetDevice(e->dev), ZLY_ERR_SYSTEM);
-    return join_nms(e, stream ? (hipStream_t)stream : e->stream, lag);
+    hipStream_t s = stream ? (hipStream_t)stream : e->stream;
+    // every call but the last `lag`: calls are stream-ordered among themselves, so waiting for call (last - lag) covers all earlier ones
+    if (lag <= 1 && e->call_seq > (uint64_t)lag)
+        HIP_TRY(hipStreamWaitEvent(s, e->ev_call[(e->call_seq - 1 - (uint64_t)lag) & 1], 0), ZLY_ERR_INFERENCE);
+    return join_nms(e, s, lag);
 }
 
 size_t zly_slab_bytes(const zly_engine* e) { return e ? slab_bytes_of(e) : 0; }
