@@ -185,7 +185,7 @@ def cpu_baseline(frames_np, seconds=12.0):
             "note": "ORT-CPU unavailable offline; torch-CPU stand-in for the forward pass. 60 FPS is the reference's unmeasured sleep-throttle target (README.md:16, onnx_engine.cpp:462-466)"}
 
 
-def host_to_host(threads, seconds=4.0, max_batch=64):
+def host_to_host(threads, seconds=4.0, max_batch=64, engines=1):
     """SURVEY 8d's throughput metric proper: request bytes in HOST memory -> detections in HOST memory, `threads` submitting host
     threads (config 3: >= 8).  Measured natively by _build/zly_h2h_bench (tests/cpp/bench_h2h.cpp: no interpreter between the
     threads and the C ABI), once through zly_submit / zly_wait and once through HipInferenceEngine::submitInference ->
@@ -198,7 +198,7 @@ def host_to_host(threads, seconds=4.0, max_batch=64):
                    "the previous batch's compute -> path -> slab D2H -> zly_wait; 63 GB/s PCIe Gen5 x16 / 519168 B = 121 k frames/s ceiling"}
     for mode in ("cabi", "plugin"):
         try:
-            r = subprocess.run([exe, zly.DEFAULT_WEIGHTS, mode, str(threads), str(seconds), str(max_batch)],
+            r = subprocess.run([exe, zly.DEFAULT_WEIGHTS, mode, str(threads), str(seconds), str(max_batch), str(engines)],
                                capture_output=True, text=True, timeout=120)
             line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
             out[mode] = json.loads(line[-1]) if (r.returncode == 0 and line) else {"error": (r.stderr or r.stdout)[-400:], "rc": r.returncode}
@@ -416,7 +416,7 @@ def run():
                                                                   "kept_max": int(max(int(h["n_kept"]) for h in hdrs))}
     if rank == 0 and world == 1 and not a.no_extras and os.environ.get("ZLY_BENCH_NO_H2H") != "1":
         log("host-to-host throughput leg (native driver, 2 x ~5 s)")
-        h2h = host_to_host(max(8, min(12, host_cores() - 3)))
+        h2h = host_to_host(max(8, min(12, host_cores() - 3)), engines=n_eng)
         result["throughput_host_to_host"] = h2h
         if "frames_per_sec" in h2h.get("cabi", {}):
             result["throughput_host_to_host"]["frac_of_device_resident"] = round(h2h["cabi"]["frames_per_sec"] / value, 3)

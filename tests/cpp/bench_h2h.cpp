@@ -2,7 +2,10 @@
 // detections in host memory", config 3: >= 8 submitting host threads), measured natively so that no interpreter sits
 // between the threads and the C ABI.  bench.py runs it as a child process and embeds its JSON line.
 //
-//   zly_h2h_bench <weights.zlyw> <cabi|plugin> <threads> <seconds> <max_batch> [w h]
+//   zly_h2h_bench <weights.zlyw> <cabi|plugin> <threads> <seconds> <max_batch> [engines [w h]]
+//
+// engines > 1: that many engine instances on the GPU (ZLY_FLAG_SINGLE_CHAIN), submitting thread t feeds engine t % engines; their
+// batches overlap on the device (bench.py --engines)
 //
 // cabi  : T threads call zly_submit (one copy of the frame into the engine's pinned ring, on the calling thread), one
 //         consumer thread calls zly_wait in ticket order -- the shape of the reference's submitInference / result hand-over
@@ -22,6 +25,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <memory>
 #include <mutex>
 #include <random>
 #include <thread>
@@ -44,7 +48,8 @@ int main(int argc, char** argv)
     const int T = std::max(1, atoi(argv[3]));
     const double seconds = atof(argv[4]);
     const int max_batch = std::max(1, atoi(argv[5]));
-    const int W = argc > 7 ? atoi(argv[6]) : 416, H = argc > 7 ? atoi(argv[7]) : 416;
+    const int E = argc > 6 ? std::max(1, atoi(argv[6])) : 1;
+    const int W = argc > 8 ? atoi(argv[7]) : 416, H = argc > 8 ? atoi(argv[8]) : 416;
     const size_t fb = (size_t)W * H * 3;
 
     std::vector<std::vector<std::vector<uint8_t>>> frames((size_t)T);
@@ -66,82 +71,101 @@ int main(int argc, char** argv)
     uint64_t warm_completed = 0;
 
     if (mode == "cabi") {
-        zly_config c;
-        zly_default_config(&c);
-        c.weights_path = weights.c_str();
-        c.model_w = 416; c.model_h = 416;
-        c.max_batch = max_batch; c.max_dets = 64; c.warmup_runs = 3;
-        c.flags = ZLY_FLAG_NO_HEAD_TENSOR | ZLY_FLAG_ASYNC_NMS;
-        zly_engine* e = nullptr;
-        if (zly_create(&c, &e) != ZLY_OK) { std::fprintf(stderr, "zly_create: %s\n", zly_last_error()); return 3; }
         struct Item { uint64_t ticket; Clock::time_point ts; };
-        std::mutex qmu;
-        std::condition_variable qcv;
-        std::deque<Item> q;
-        std::vector<std::thread> subs;
+        struct Eng {
+            zly_engine* e = nullptr;
+            std::mutex qmu;
+            std::condition_variable qcv;
+            std::deque<Item> q;
+            std::atomic<uint64_t> submitted{0}, done{0};
+        };
+        std::vector<std::unique_ptr<Eng>> engs;
+        for (int i = 0; i < E; ++i) {
+            zly_config c;
+            zly_default_config(&c);
+            c.weights_path = weights.c_str();
+            c.model_w = 416; c.model_h = 416;
+            c.max_batch = max_batch; c.max_dets = 64; c.warmup_runs = 3;
+            c.flags = ZLY_FLAG_NO_HEAD_TENSOR | (E > 1 ? ZLY_FLAG_SINGLE_CHAIN : ZLY_FLAG_ASYNC_NMS);
+            engs.emplace_back(new Eng());
+            if (zly_create(&c, &engs.back()->e) != ZLY_OK) { std::fprintf(stderr, "zly_create: %s\n", zly_last_error()); return 3; }
+        }
+        std::vector<std::thread> subs, cons;
         for (int t = 0; t < T; ++t)
             subs.emplace_back([&, t] {
+                Eng& g = *engs[(size_t)(t % E)];
                 while (!go) std::this_thread::yield();
                 size_t k = 0;
                 while (!stop) {
                     const auto& f = frames[(size_t)t][k++ & 3];
                     uint64_t ticket = 0;
                     const auto ts = Clock::now();
-                    if (zly_submit(e, f.data(), f.size(), W, H, &ticket) != ZLY_OK) { errors++; break; }
-                    submitted++;
-                    { std::lock_guard<std::mutex> lk(qmu); q.push_back(Item{ticket, ts}); }
-                    qcv.notify_one();
+                    if (zly_submit(g.e, f.data(), f.size(), W, H, &ticket) != ZLY_OK) { errors++; break; }
+                    submitted++; g.submitted++;
+                    { std::lock_guard<std::mutex> lk(g.qmu); g.q.push_back(Item{ticket, ts}); }
+                    g.qcv.notify_one();
                 }
             });
-        std::thread consumer([&] {
-            std::vector<zly_det> dets(64);
-            while (true) {
-                Item it;
-                {
-                    std::unique_lock<std::mutex> lk(qmu);
-                    qcv.wait(lk, [&] { return !q.empty() || (stop && submitted == completed + errors); });
-                    if (q.empty()) return;
-                    it = q.front(); q.pop_front();
+        for (int i = 0; i < E; ++i)
+            cons.emplace_back([&, i] {
+                Eng& g = *engs[(size_t)i];
+                std::vector<zly_det> dets(64);
+                while (true) {
+                    Item it;
+                    {
+                        std::unique_lock<std::mutex> lk(g.qmu);
+                        g.qcv.wait(lk, [&] { return !g.q.empty() || (stop && g.submitted == g.done); });
+                        if (g.q.empty()) return;
+                        it = g.q.front(); g.q.pop_front();
+                    }
+                    int32_t n = 0;
+                    const int32_t rc = zly_wait(g.e, it.ticket, dets.data(), 64, &n);
+                    g.done++;
+                    if (rc != ZLY_OK) { errors++; continue; }
+                    const double ms = secs(it.ts, Clock::now()) * 1e3;
+                    dets_total += (uint64_t)std::min(n, 64);
+                    completed++;
+                    std::lock_guard<std::mutex> lk(lat_mu);
+                    lat.add(ms);
                 }
-                int32_t n = 0;
-                if (zly_wait(e, it.ticket, dets.data(), 64, &n) != ZLY_OK) { errors++; continue; }
-                const double ms = secs(it.ts, Clock::now()) * 1e3;
-                dets_total += (uint64_t)std::min(n, 64);
-                completed++;
-                std::lock_guard<std::mutex> lk(lat_mu);
-                lat.add(ms);
-            }
-        });
+            });
         go = true;
-        std::this_thread::sleep_for(std::chrono::milliseconds(500));                 // warm-up: graphs captured, ring in steady state
+        std::this_thread::sleep_for(std::chrono::milliseconds(500));                 // warm-up: graphs captured, rings in steady state
         { std::lock_guard<std::mutex> lk(lat_mu); lat.ms.clear(); }
         warm_completed = completed; t0 = Clock::now();
         std::this_thread::sleep_for(std::chrono::duration<double>(seconds));
         const uint64_t end_completed = completed; t1 = Clock::now();
         stop = true;
         for (auto& th : subs) th.join();
-        qcv.notify_all();
-        consumer.join();
+        for (auto& g : engs) g->qcv.notify_all();
+        for (auto& th : cons) th.join();
         zly_stats st{};
-        zly_get_stats(e, &st);
+        uint64_t batches = 0, count = 0, sampled = 0;
+        double pre = 0, fwd = 0, post = 0;
+        for (auto& g : engs) {
+            zly_get_stats(g->e, &st);
+            batches += st.batches; count += st.inference_count; sampled += st.sampled_frames;
+            pre += st.sampled_preprocess_ms; fwd += st.sampled_forward_ms; post += st.sampled_postprocess_ms;
+        }
         const double dt = secs(t0, t1);
         const double fps = (double)(end_completed - warm_completed) / dt;
-        std::lock_guard<std::mutex> lk(lat_mu);
-        std::printf("{\"mode\":\"cabi\",\"threads\":%d,\"max_batch\":%d,\"frame\":\"%dx%d\",\"seconds\":%.3f,\"frames\":%llu,\"frames_per_sec\":%.1f,"
-                    "\"pcie_h2d_GBps\":%.2f,\"avg_batch\":%.1f,\"p50_ms\":%.3f,\"p99_ms\":%.3f,\"errors\":%llu,\"detections\":%llu,"
-                    "\"avg_preprocess_ms_per_frame\":%.5f,\"avg_forward_ms_per_frame\":%.5f,\"avg_postprocess_ms_per_frame\":%.5f}\n",
-                    T, max_batch, W, H, dt, (unsigned long long)(end_completed - warm_completed), fps, fps * (double)fb / 1e9,
-                    st.batches ? (double)st.inference_count / (double)st.batches : 0.0, lat.pct(0.5), lat.pct(0.99),
-                    (unsigned long long)errors.load(), (unsigned long long)dets_total.load(),
-                    st.sampled_frames ? st.sampled_preprocess_ms / (double)st.sampled_frames : 0.0,
-                    st.sampled_frames ? st.sampled_forward_ms / (double)st.sampled_frames : 0.0,
-                    st.sampled_frames ? st.sampled_postprocess_ms / (double)st.sampled_frames : 0.0);
-        zly_destroy(e);
+        {
+            std::lock_guard<std::mutex> lk(lat_mu);
+            std::printf("{\"mode\":\"cabi\",\"threads\":%d,\"engines\":%d,\"max_batch\":%d,\"frame\":\"%dx%d\",\"seconds\":%.3f,\"frames\":%llu,\"frames_per_sec\":%.1f,"
+                        "\"pcie_h2d_GBps\":%.2f,\"avg_batch\":%.1f,\"p50_ms\":%.3f,\"p99_ms\":%.3f,\"errors\":%llu,\"detections\":%llu,"
+                        "\"avg_preprocess_ms_per_frame\":%.5f,\"avg_forward_ms_per_frame\":%.5f,\"avg_postprocess_ms_per_frame\":%.5f}\n",
+                        T, E, max_batch, W, H, dt, (unsigned long long)(end_completed - warm_completed), fps, fps * (double)fb / 1e9,
+                        batches ? (double)count / (double)batches : 0.0, lat.pct(0.5), lat.pct(0.99),
+                        (unsigned long long)errors.load(), (unsigned long long)dets_total.load(),
+                        sampled ? pre / (double)sampled : 0.0, sampled ? fwd / (double)sampled : 0.0, sampled ? post / (double)sampled : 0.0);
+        }
+        for (auto& g : engs) zly_destroy(g->e);
         return errors ? 4 : 0;
     }
 
     // ---- plugin mode -------------------------------------------------------------------------------------------------
     setenv("ZLY_MAX_BATCH", std::to_string(max_batch).c_str(), 1);
+    setenv("ZLY_ENGINES_PER_GPU", std::to_string(E).c_str(), 1);
     setenv("ZLY_MAX_DETS", "64", 1);
     setenv("ZLY_MODEL_WATCH_MS", "0", 1);
     ServerConfig config;
@@ -190,10 +214,10 @@ int main(int argc, char** argv)
     const double dt = secs(t0, t1);
     const double fps = (double)(end_completed - warm_completed) / dt;
     std::lock_guard<std::mutex> lk(lat_mu);
-    std::printf("{\"mode\":\"plugin\",\"threads\":%d,\"max_batch\":%d,\"frame\":\"%dx%d\",\"seconds\":%.3f,\"frames\":%llu,\"frames_per_sec\":%.1f,"
+    std::printf("{\"mode\":\"plugin\",\"threads\":%d,\"engines\":%d,\"max_batch\":%d,\"frame\":\"%dx%d\",\"seconds\":%.3f,\"frames\":%llu,\"frames_per_sec\":%.1f,"
                 "\"pcie_h2d_GBps\":%.2f,\"p50_ms\":%.3f,\"p99_ms\":%.3f,\"errors\":%llu,\"detections\":%llu,\"batches\":%s,"
                 "\"avg_preprocessing_time_ms\":%s,\"avg_postprocessing_time_ms\":%s}\n",
-                T, max_batch, W, H, dt, (unsigned long long)(end_completed - warm_completed), fps, fps * (double)fb / 1e9, lat.pct(0.5), lat.pct(0.99),
+                T, E, max_batch, W, H, dt, (unsigned long long)(end_completed - warm_completed), fps, fps * (double)fb / 1e9, lat.pct(0.5), lat.pct(0.99),
                 (unsigned long long)errors.load(), (unsigned long long)dets_total.load(), status["batches"].c_str(),
                 status["avg_preprocessing_time_ms"].c_str(), status["avg_postprocessing_time_ms"].c_str());
     return errors ? 4 : 0;

@@ -60,11 +60,14 @@ Result<void> HipInferenceEngine::initialize()
     const int ndev = std::max(1, envInt("ZLY_NUM_DEVICES", 1));
     const int dev0 = std::max(0, envInt("ZLY_FIRST_DEVICE", 0));
     first_device_ = dev0;
+    // ZLY_ENGINES_PER_GPU (default 1): several engine instances per GPU, each one chain of launches on its own stream; consecutive
+    // batches go to different instances and overlap on the device (one instance leaves the chip idle at every kernel boundary)
+    engines_per_gpu_ = std::max(1, std::min(8, envInt("ZLY_ENGINES_PER_GPU", 1)));
     std::vector<std::shared_ptr<EngineHandle>> fresh;
-    for (int d = 0; d < ndev; ++d) {
+    for (int d = 0; d < ndev * engines_per_gpu_; ++d) {
         int32_t rc = ZLY_OK;
         std::string msg;
-        auto e = createEngineOn(dev0 + d, &rc, &msg);
+        auto e = createEngineOn(dev0 + d / engines_per_gpu_, &rc, &msg);
         if (!e) return Result<void>::error(toErrorCode(rc), "Failed to initialize HIP inference engine: " + msg);
         fresh.push_back(std::move(e));
     }
@@ -105,7 +108,8 @@ std::shared_ptr<HipInferenceEngine::EngineHandle> HipInferenceEngine::createEngi
     c.dtype = envInt("ZLY_FP32", 0) ? ZLY_DTYPE_FP32 : ZLY_DTYPE_BF16;
     c.warmup_runs = 3;                                   // onnx_engine.cpp:919-954
     c.use_graph = 1;
-    c.flags = ZLY_FLAG_NO_HEAD_TENSOR | ZLY_FLAG_ASYNC_NMS;   // the server only consumes detections; NMS of a batch runs beside the next one
+    // the server only consumes detections; one engine per GPU: NMS of a batch runs beside the next one; several: one chain each
+    c.flags = ZLY_FLAG_NO_HEAD_TENSOR | (engines_per_gpu_ > 1 ? ZLY_FLAG_SINGLE_CHAIN : ZLY_FLAG_ASYNC_NMS);
     zly_engine* e = nullptr;
     *rc = zly_create(&c, &e);
     if (*rc != ZLY_OK) { *msg = zly_last_error(); return nullptr; }
@@ -129,7 +133,7 @@ Result<void> HipInferenceEngine::reloadModel()
     for (size_t d = 0; d < count; ++d) {
         int32_t rc = ZLY_OK;
         std::string msg;
-        auto e = createEngineOn(first_device_ + (int)d, &rc, &msg);
+        auto e = createEngineOn(first_device_ + (int)d / engines_per_gpu_, &rc, &msg);
         if (!e) return Result<void>::error(toErrorCode(rc), "Failed to reload model: " + msg);
         fresh.push_back(std::move(e));
     }
@@ -210,7 +214,7 @@ Result<void> HipInferenceEngine::submitInference(const InferenceRequest& request
     p.enqueue_ms = wallMs();
     {
         std::lock_guard<std::mutex> lk(engines_mutex_);
-        if (!engines_.empty()) p.engine = engines_[(size_t)(seq % engines_.size())];        // one-frame-per-GPU round robin
+        if (!engines_.empty()) p.engine = engines_[(size_t)(seq % engines_.size())];        // one-frame-per-engine round robin
     }
     if (!p.engine) {
         p.failed = true;
@@ -357,7 +361,8 @@ std::unordered_map<std::string, std::string> HipInferenceEngine::getStatus() con
     s["avg_postprocessing_time_ms"] = frames ? std::to_string(post / (double)frames) : "0";
     s["weight_format"] = (!engines.empty() && zly_weights_fp8(engines[0]->e)) ? "fp8_e4m3" : "fp32";      // the reference's "quantised" model claim (README.md:84)
     s["worker_threads"] = std::to_string(engines.size());
-    s["devices"] = std::to_string(engines.size());
+    s["devices"] = std::to_string(engines.size() / (size_t)std::max(1, engines_per_gpu_));
+    s["engines_per_gpu"] = std::to_string(engines_per_gpu_);
     return s;
 }
 

@@ -79,6 +79,7 @@ private:
     mutable std::mutex engines_mutex_;                     // guards the vector (held for pointer copies only, never across a device call)
     std::vector<std::shared_ptr<EngineHandle>> engines_;   // one per GPU
     int first_device_ = 0;
+    int engines_per_gpu_ = 1;
     std::thread monitor_, completer_;
     std::mutex reload_mutex_;                              // one reload at a time
     std::atomic<uint32_t> model_version_{1};
