@@ -100,7 +100,7 @@ int main(int argc, char** argv)
                     const auto& f = frames[(size_t)t][k++ & 3];
                     uint64_t ticket = 0;
                     const auto ts = Clock::now();
-                    if (zly_submit(g.e, f.data(), f.size(), W, H, &ticket) != ZLY_OK) { errors++; break; }
+                    if (zly_submit(g.e, f.data(), f.size(), W, H, &ticket) != ZLY_OK) { if (errors++ == 0) std::fprintf(stderr, "zly_submit: %s\n", zly_last_error()); break; }
                     submitted++; g.submitted++;
                     { std::lock_guard<std::mutex> lk(g.qmu); g.q.push_back(Item{ticket, ts}); }
                     g.qcv.notify_one();
@@ -121,7 +121,7 @@ int main(int argc, char** argv)
                     int32_t n = 0;
                     const int32_t rc = zly_wait(g.e, it.ticket, dets.data(), 64, &n);
                     g.done++;
-                    if (rc != ZLY_OK) { errors++; continue; }
+                    if (rc != ZLY_OK) { if (errors++ == 0) std::fprintf(stderr, "zly_wait: %d %s\n", rc, zly_last_error()); continue; }
                     const double ms = secs(it.ts, Clock::now()) * 1e3;
                     dets_total += (uint64_t)std::min(n, 64);
                     completed++;

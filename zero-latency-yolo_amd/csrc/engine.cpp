@@ -848,18 +848,30 @@ static int run_path(zly_engine* e, int n, const uint8_t* d_src, void* d_slabs_ou
         const int key = (n * 2 + (fused ? 1 : 0)) * 2 + par;     // the captured Detect tail holds the candidate buffer's address
         auto it = e->graphs.find(key);
         if (it == e->graphs.end()) {
-            // capture on the engine's own stream, then replay on whichever stream the caller uses
+            // capture on the engine's own stream, then replay on whichever stream the caller uses.  Captures are serialised process-wide
+            // (several engines per GPU capture from their own dispatcher threads: two captures in flight at once failed with "operation
+            // failed due to a previous error during capture"); a capture that still fails leaves this batch size on eager launches
+            static std::mutex capture_mu;
             hipGraph_t g = nullptr;
             hipGraphExec_t ge = nullptr;
             HIP_TRY(hipStreamSynchronize(s), ZLY_ERR_INFERENCE);
-            HIP_TRY(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal), ZLY_ERR_INFERENCE);
-            hipError_t r = run_ops(e, first, nops - 1, n, nullptr, nullptr, 0, e->stream);
-            hipError_t r2 = hipStreamEndCapture(e->stream, &g);
-            if (r != hipSuccess || r2 != hipSuccess) return fail(ZLY_ERR_INFERENCE, std::string("graph capture failed: ") + hipGetErrorString(r != hipSuccess ? r : r2));
-            HIP_TRY(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0), ZLY_ERR_INFERENCE);
-            hipGraphDestroy(g);
+            {
+                std::lock_guard<std::mutex> cl(capture_mu);
+                hipError_t r = hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal);
+                if (r == hipSuccess) {
+                    r = run_ops(e, first, nops - 1, n, nullptr, nullptr, 0, e->stream);
+                    hipError_t r2 = hipStreamEndCapture(e->stream, &g);
+                    if (r == hipSuccess) r = r2;
+                }
+                if (r == hipSuccess) r = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+                if (g) hipGraphDestroy(g);
+                if (r != hipSuccess) { (void)hipGetLastError(); ge = nullptr; }
+            }
             it = e->graphs.emplace(key, ge).first;
         }
+        if (!it->second) {
+            HIP_TRY(run_ops(e, first, nops - 1, n, nullptr, nullptr, 0, s), ZLY_ERR_INFERENCE);      // capture failed once for this shape: eager
+        } else
         HIP_TRY(hipGraphLaunch(it->second, s), ZLY_ERR_INFERENCE);
     } else {
         HIP_TRY(run_ops(e, first, nops - 1, n, nullptr, nullptr, 0, s), ZLY_ERR_INFERENCE);
@@ -951,7 +963,7 @@ static void destroy_engine(zly_engine* e)
     if (e->stream) hipStreamSynchronize(e->stream);
     for (int i = 0; i < 2; ++i) if (e->side[i]) hipStreamSynchronize(e->side[i]);
     if (e->nms_stream) hipStreamSynchronize(e->nms_stream);
-    for (auto& kv : e->graphs) hipGraphExecDestroy(kv.second);
+    for (auto& kv : e->graphs) if (kv.second) hipGraphExecDestroy(kv.second);
     for (Buffer& b : e->bufs) if (b.ptr) hipFree(b.ptr);
     void* dptrs[] = {e->d_weights, e->d_head, e->d_cand, e->d_cand_alt, e->d_count_alt, e->d_scratch, e->d_count, e->d_slabs, e->d_desc, e->d_stage, e->d_scratch_f32};
     for (void* p : dptrs) if (p) hipFree(p);
