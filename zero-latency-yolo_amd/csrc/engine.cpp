@@ -805,6 +805,8 @@ static void harvest_timing(zly_engine* e)
 static int run_path(zly_engine* e, int n, const uint8_t* d_src, void* d_slabs_out, uint32_t tag0, hipStream_t s, bool with_pre, bool defer_nms = false,
                     hipStream_t* nms_stream_out = nullptr)
 {
+    static std::mutex g_enqueue_mu;                    // see the capture note below: one engine of the process enqueues at a time (~0.1 ms per batch)
+    std::lock_guard<std::mutex> gl(g_enqueue_mu);
     const size_t nops = e->ops.size();
     harvest_timing(e);
     const bool sample = with_pre && !e->t_pending && (e->sample_ctr++ % zly_engine::SAMPLE_EVERY) == 0;
@@ -848,16 +850,15 @@ static int run_path(zly_engine* e, int n, const uint8_t* d_src, void* d_slabs_ou
         const int key = (n * 2 + (fused ? 1 : 0)) * 2 + par;     // the captured Detect tail holds the candidate buffer's address
         auto it = e->graphs.find(key);
         if (it == e->graphs.end()) {
-            // capture on the engine's own stream, then replay on whichever stream the caller uses.  Captures are serialised process-wide
-            // (several engines per GPU capture from their own dispatcher threads: two captures in flight at once failed with "operation
-            // failed due to a previous error during capture"); a capture that still fails leaves this batch size on eager launches
-            static std::mutex capture_mu;
+            // capture on the engine's own stream, then replay on whichever stream the caller uses.  With several engines per process every
+            // enqueue section holds the process-wide g_enqueue_mu (run_path's callers), so no other thread launches anything while a
+            // capture is open: a launch from another engine's dispatcher thread during a thread-local capture failed BOTH with "operation
+            // failed due to a previous error during capture".  A capture that still fails leaves this batch size on eager launches
             hipGraph_t g = nullptr;
             hipGraphExec_t ge = nullptr;
             HIP_TRY(hipStreamSynchronize(s), ZLY_ERR_INFERENCE);
             {
-                std::lock_guard<std::mutex> cl(capture_mu);
-                hipError_t r = hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal);
+                hipError_t r = hipStreamBeginCapture(e->stream, hipStreamCaptureModeRelaxed);
                 if (r == hipSuccess) {
                     r = run_ops(e, first, nops - 1, n, nullptr, nullptr, 0, e->stream);
                     hipError_t r2 = hipStreamEndCapture(e->stream, &g);
