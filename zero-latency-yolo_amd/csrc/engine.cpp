@@ -142,6 +142,7 @@ struct zly_engine {
     StemArgs stem{};
     bool stem1 = false;               // ... and model.1 (32 channels) as well: the stem map stays in LDS (kernels_stem.hip: stem_model1_kernel)
     Stem1Args stem1a{};
+    bool ingest_active = false;       // set while the pipelined host path (zly_submit) enqueues: see run_path
     bool last_stem1 = false;          // the most recent call ran it (model.0 then only exists in HBM with ZLY_FLAG_DUMP_LOGITS)
     hipStream_t stream = nullptr;
     hipStream_t side[2] = {nullptr, nullptr};     // P3 / P4 Detect branches (forked from and joined to the main stream)
@@ -785,6 +786,12 @@ static int join_nms(zly_engine* e, hipStream_t s, int lag = 0)
     return ZLY_OK;
 }
 
+// One engine of the process enqueues at a time (~0.1 ms of host work per batch): taken around every enqueue section of every entry point.
+// Reason: stream capture.  With several engines per process (bench --engines, ZLY_ENGINES_PER_GPU) a HIP call from another engine's
+// dispatcher thread while a capture was open -- a launch, an async copy, an event wait -- failed both sides with "operation failed due
+// to a previous error during capture" (thread-local and relaxed capture modes alike).
+static std::mutex g_enqueue_mu;
+
 // phase timing of the last sampled call, if its events have completed: added to the stats, never waited for
 static void harvest_timing(zly_engine* e)
 {
@@ -805,8 +812,6 @@ static void harvest_timing(zly_engine* e)
 static int run_path(zly_engine* e, int n, const uint8_t* d_src, void* d_slabs_out, uint32_t tag0, hipStream_t s, bool with_pre, bool defer_nms = false,
                     hipStream_t* nms_stream_out = nullptr)
 {
-    static std::mutex g_enqueue_mu;                    // see the capture note below: one engine of the process enqueues at a time (~0.1 ms per batch)
-    std::lock_guard<std::mutex> gl(g_enqueue_mu);
     const size_t nops = e->ops.size();
     harvest_timing(e);
     const bool sample = with_pre && !e->t_pending && (e->sample_ctr++ % zly_engine::SAMPLE_EVERY) == 0;
@@ -846,7 +851,9 @@ static int run_path(zly_engine* e, int n, const uint8_t* d_src, void* d_slabs_ou
         HIP_TRY(run_op(e, e->ops[0], n, d_src, nullptr, 0, s), ZLY_ERR_INFERENCE);
     }
     if (sample) HIP_TRY(hipEventRecord(e->ev_t[1], s), ZLY_ERR_INFERENCE);
-    if (e->cfg.use_graph) {
+    // the pipelined host path (several dispatcher threads per process) replays graphs for FULL batches only -- the steady state under
+    // load -- and launches partial batches eagerly: no capture storm over the 63 partial sizes, and no capture while other engines run
+    if (e->cfg.use_graph && !(e->ingest_active && n != e->cfg.max_batch)) {
         const int key = (n * 2 + (fused ? 1 : 0)) * 2 + par;     // the captured Detect tail holds the candidate buffer's address
         auto it = e->graphs.find(key);
         if (it == e->graphs.end()) {
@@ -1061,6 +1068,7 @@ static void ingest_close_open(Ingest* g)
 static void ingest_enqueue(zly_engine* e, Ingest* g, IngestSlot& sl)
 {
     std::lock_guard<std::mutex> lk(e->mu);
+    std::lock_guard<std::mutex> gl(g_enqueue_mu);
     const int n = sl.n_reserved;
     auto body = [&]() -> int {
         HIP_TRY(hipSetDevice(e->dev), ZLY_ERR_SYSTEM);
@@ -1070,7 +1078,9 @@ static void ingest_enqueue(zly_engine* e, Ingest* g, IngestSlot& sl)
         int rc = set_desc(e, n, sl.w.data(), sl.h.data(), sl.off.data(), e->stream);
         if (rc != ZLY_OK) return rc;
         hipStream_t ns = e->stream;
+        e->ingest_active = true;
         rc = run_path(e, n, sl.d_stage, sl.d_slabs, (uint32_t)(sl.batch << 16), e->stream, true, (e->cfg.flags & ZLY_FLAG_ASYNC_NMS) != 0, &ns);
+        e->ingest_active = false;
         if (rc != ZLY_OK) return rc;
         HIP_TRY(hipEventRecord(sl.ev_done, ns), ZLY_ERR_INFERENCE);
         HIP_TRY(hipStreamWaitEvent(g->d2h_stream, sl.ev_done, 0), ZLY_ERR_INFERENCE);
@@ -1448,6 +1458,7 @@ int32_t zly_destroy(zly_engine* e)
 static int detect_host_locked(zly_engine* e, int32_t n, const uint8_t* const* bgr, const size_t* nbytes,
                               const int32_t* w, const int32_t* h, zly_det* out, int32_t cap, int32_t* n_out)
 {
+    std::unique_lock<std::mutex> gl(g_enqueue_mu);
     HIP_TRY(hipSetDevice(e->dev), ZLY_ERR_SYSTEM);
     std::vector<size_t> offs((size_t)n);
     size_t total = 0;
@@ -1471,6 +1482,7 @@ static int detect_host_locked(zly_engine* e, int32_t n, const uint8_t* const* bg
     if (rc != ZLY_OK) { with_stats(e, [](zly_stats& st) { st.inference_errors++; }); return rc; }
     const size_t sb = slab_bytes_of(e);
     HIP_TRY(hipMemcpyAsync(e->h_slabs, e->d_slabs, sb * (size_t)n, hipMemcpyDeviceToHost, e->stream), ZLY_ERR_INFERENCE);
+    gl.unlock();                                                         // waiting for the device is not an enqueue section
     HIP_TRY(hipStreamSynchronize(e->stream), ZLY_ERR_INFERENCE);
     const uint64_t ts = now_ms();                                        // onnx_engine.cpp:813-815
     for (int i = 0; i < n; ++i) {
@@ -1536,6 +1548,7 @@ int32_t zly_detect_device(zly_engine* e, int32_t n, const void* d_frames, int32_
     if (!d_frames || w <= 0 || h <= 0) return fail(ZLY_ERR_INVALID_INPUT, "bad frame pointer or size");
     if (n < 1 || n > e->cfg.max_batch) return fail(ZLY_ERR_INVALID_ARGUMENT, "batch size out of range");
     std::lock_guard<std::mutex> lk(e->mu);
+    std::lock_guard<std::mutex> gl(g_enqueue_mu);
     HIP_TRY(hipSetDevice(e->dev), ZLY_ERR_SYSTEM);
     hipStream_t s = stream ? (hipStream_t)stream : e->stream;
     std::vector<int32_t> ws((size_t)n, w), hs((size_t)n, h);
@@ -1621,6 +1634,7 @@ int32_t zly_forward(zly_engine* e, int32_t n, const float* images_nchw, float* h
     if (!images_nchw || !head_out) return fail(ZLY_ERR_INVALID_ARGUMENT, "null argument");
     if (n < 1 || n > e->cfg.max_batch) return fail(ZLY_ERR_INVALID_ARGUMENT, "batch size out of range");
     std::lock_guard<std::mutex> lk(e->mu);
+    std::lock_guard<std::mutex> gl(g_enqueue_mu);
     HIP_TRY(hipSetDevice(e->dev), ZLY_ERR_SYSTEM);
     const size_t elems = (size_t)n * 3 * e->cfg.model_w * e->cfg.model_h;
     int rc = ensure_scratch_f32(e, elems);
@@ -1804,6 +1818,7 @@ int32_t zly_profile_ops(zly_engine* e, int32_t n, const void* d_frames, int32_t 
     if (!e) return fail(ZLY_ERR_NOT_INITIALIZED, "Engine not running");
     if (!d_frames || !ms_out || reps < 1 || n < 1 || n > e->cfg.max_batch) return fail(ZLY_ERR_INVALID_ARGUMENT, "bad argument");
     std::lock_guard<std::mutex> lk(e->mu);
+    std::lock_guard<std::mutex> gl(g_enqueue_mu);
     HIP_TRY(hipSetDevice(e->dev), ZLY_ERR_SYSTEM);
     std::vector<int32_t> ws((size_t)n, w), hs((size_t)n, h);
     std::vector<size_t> offs((size_t)n);
