@@ -1154,6 +1154,7 @@ static void ingest_free(zly_engine* e, Ingest* g);
 static int ingest_start(zly_engine* e)
 {
     std::lock_guard<std::mutex> lk(e->mu);
+    std::lock_guard<std::mutex> gl(g_enqueue_mu);      // allocations: never while another engine of the process has a capture open
     if (e->ingest.load()) return ZLY_OK;
     HIP_TRY(hipSetDevice(e->dev), ZLY_ERR_SYSTEM);
     Ingest* g = new Ingest();
