@@ -1041,6 +1041,11 @@ struct Ingest {
     hipStream_t copy_stream = nullptr, d2h_stream = nullptr;
 };
 
+// One H2D and one D2H stream per device, shared by every engine of the process: each HIP stream beyond the hardware-queue limit (4 by default)
+// shares a hardware queue with another stream and the two serialise -- an upload stream of engine B landing on the queue of engine A's
+// compute stream stalled A for a whole 33 MB transfer.  Uploads of different engines share the PCIe link anyway.
+static hipStream_t g_h2d_stream[16] = {}, g_d2h_stream[16] = {};
+
 static int env_int(const char* name, int fallback) { const char* v = getenv(name); return (v && *v) ? atoi(v) : fallback; }
 
 // under ing->mu: make the next ring slot the open one if it is free
@@ -1166,8 +1171,10 @@ static int ingest_start(zly_engine* e)
     g->slot_bytes = (bytes + 4095) / 4096 * 4096;
     g->depth = std::max(1, std::min(S - 2, env_int("ZLY_INFLIGHT", 2)));
     g->slots.resize((size_t)S);
-    bool ok = hipStreamCreateWithFlags(&g->copy_stream, hipStreamNonBlocking) == hipSuccess &&
-              hipStreamCreateWithFlags(&g->d2h_stream, hipStreamNonBlocking) == hipSuccess;
+    const int dv = e->dev & 15;
+    bool ok = (g_h2d_stream[dv] || hipStreamCreateWithFlags(&g_h2d_stream[dv], hipStreamNonBlocking) == hipSuccess) &&
+              (g_d2h_stream[dv] || hipStreamCreateWithFlags(&g_d2h_stream[dv], hipStreamNonBlocking) == hipSuccess);
+    g->copy_stream = g_h2d_stream[dv]; g->d2h_stream = g_d2h_stream[dv];
     const size_t sb = slab_bytes_of(e) * (size_t)e->cfg.max_batch;
     for (IngestSlot& sl : g->slots) {
         ok = ok && hipHostMalloc((void**)&sl.h_stage, g->slot_bytes, hipHostMallocDefault) == hipSuccess &&
@@ -1217,9 +1224,7 @@ static void ingest_free(zly_engine* e, Ingest* g)
         if (sl.ev_done) hipEventDestroy(sl.ev_done);
         if (sl.ev_out) hipEventDestroy(sl.ev_out);
     }
-    if (g->copy_stream) hipStreamDestroy(g->copy_stream);
-    if (g->d2h_stream) hipStreamDestroy(g->d2h_stream);
-    delete g;
+    delete g;                                          // the copy streams are shared by the process and stay
 }
 
 static int ingest_submit(zly_engine* e, const uint8_t* bgr, size_t nbytes, int32_t w, int32_t h, uint64_t* ticket)
