@@ -65,7 +65,7 @@ def per_launch_roofline(ops, kernels, ms, nb):
         att = max(t_mfma, t_hbm)
         out.append({"op": r["op"], "kernel": r["kernel"], "us": round(r["us"], 2), "gflop": round(r["gflop"], 3), "MB": round(r["MB"], 2),
                     "attainable_us": round(att, 2), "bound": "mfma" if t_mfma >= t_hbm else "hbm", "frac": round(att / r["us"], 4),
-                    "TFLOPs": round(r["gflop"] / r["us"] * 1e-3 * 1e3, 1), "GBps": round(r["MB"] / r["us"] * 1e3, 0), "is_conv": r["kind"] == 1})
+                    "TFLOPs": round(r["gflop"] / r["us"] * 1e3, 1), "GBps": round(r["MB"] / r["us"] * 1e3, 0), "is_conv": r["kind"] == 1})
     return out
 
 

@@ -640,6 +640,7 @@ static bool c2f_covered(zly_engine* e, const Op& op, int n)
 // ops that launch nothing at this batch size (second conv of a fused pair; per-level tail ops when one launch covers all)
 static bool op_is_noop(zly_engine* e, const Op& op, int n)
 {
+    if (op.kind == OP_PREPROCESS) return e->stem_fused;                          // detect paths: inside the stem kernel
     if (op.kind == OP_CONV && e->stem1 && op.name == "model.1") return true;     // detect paths: computed by stem_model1_kernel (booked on model.0)
     if (op.kind == OP_CONV && c2f_covered(e, op, n)) return true;
     if (op.kind == OP_CONV && op.pair == 2) return pair_active(e, op, n) != nullptr;
