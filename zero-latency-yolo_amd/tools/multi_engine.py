@@ -25,4 +25,4 @@ def run(n_eng, B=64, steps=200, warmup=20, async_nms=True, own_stream=True):
 
 a = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 for rep in range(int(sys.argv[2]) if len(sys.argv) > 2 else 4):
-    print("rep", rep, {n: round(run(n, async_nms=bool(a))) for n in (1, 2, 3)}, flush=True)
+    print("rep", rep, {n: round(run(n, async_nms=bool(a))) for n in [int(x) for x in (sys.argv[3].split(",") if len(sys.argv) > 3 else "1,2,3".split(","))]}, flush=True)
