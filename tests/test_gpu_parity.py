@@ -703,6 +703,36 @@ def test_deferred_nms_same_slabs(weights_path):
     a.close(); b.close()
 
 
+def test_latency_path_merged_detect_launches(weights_path, oracle, ref_bf16, monkeypatch):
+    """Batch <= 4 (the latency path): the three Detect stem convs run as ONE launch and the six box / class branch convs as another
+    (conv_igemm_multi_kernel, blockIdx.z picks the conv).  Every conv output and the detections must be those of the per-conv
+    launches (same kernel body, same k order: bit-identical), and every layer must match the bf16-rounding oracle."""
+    frames = zm.synth_frames(3, 416, 416, seed=91, rects=False)
+    x = _pre(oracle, frames)
+    ref_bf16.forward(torch.from_numpy(x))
+    e = zly.Engine(weights_path, max_batch=3, max_dets=256, warmup_runs=0, flags=zly.FLAG_DUMP_LOGITS)
+    ks = e.op_kernels(1)
+    assert sum("conv_igemm_multi_kernel" in k for k in ks) == 2 and sum("merged Detect launch" in k for k in ks) == 7, ks
+    res = e.detect_batch(list(frames), cap=256)
+    names = [f"model.22.cv{b}.{l}.{j}" for b in (2, 3) for l in range(3) for j in (0, 1, 2)]
+    taps = {name: [e.tap(name, i) for i in range(3)] for name in names}
+    for name in names:
+        for i in range(3):
+            _assert_layer_close(taps[name][i], ref_bf16.taps[name][i].numpy(), f"{name}[{i}]")
+    e.close()
+    monkeypatch.setenv("ZLY_NO_DET_MERGE", "1")
+    p = zly.Engine(weights_path, max_batch=3, max_dets=256, warmup_runs=0, flags=zly.FLAG_DUMP_LOGITS)
+    assert not any("conv_igemm_multi_kernel" in k for k in p.op_kernels(1))
+    res2 = p.detect_batch(list(frames), cap=256)
+    for name in names:
+        for i in range(3):
+            assert np.array_equal(p.tap(name, i), taps[name][i]), (name, i)
+    for (d1, n1), (d2, n2) in zip(res, res2):
+        assert n1 == n2 and det_fields_equal(d1, d2)
+    assert sum(n for _, n in res) > 0
+    p.close()
+
+
 def test_several_single_chain_engines_alternate(weights_path):
     """bench.py's headline configuration: three ZLY_FLAG_SINGLE_CHAIN engines on one GPU, steps alternate between them, each on its
     engine's own stream (the chains overlap), zly_join orders a foreign stream behind a step's NMS before its slabs are consumed.

@@ -164,6 +164,7 @@ struct zly_engine {
     // per GPU) or with deferred NMS
     hipEvent_t ev_call[2] = {nullptr, nullptr};
     uint64_t call_seq = 0;
+    int det_stem[3] = {-1, -1, -1}, det_a[3] = {-1, -1, -1}, det_b[3] = {-1, -1, -1};   // op indices of the Detect convs (stem, box .1, class .1) per level
     int cu_part_n = 1;                // ZLY_CU_PART: number of CU partitions (1 = whole chip)
     uint32_t cu_mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     std::atomic<Ingest*> ingest{nullptr};   // created by the first zly_submit (under mu), read lock-free afterwards
@@ -541,6 +542,27 @@ static int build_plan(zly_engine* e, std::string* err)
         for (size_t i = 0; i < e->ops.size(); ++i) by_name[e->ops[i].name] = (int)i;
         for (Op& op : e->ops)
             if (!op.c2f_leader_name.empty()) op.c2f_leader = by_name[op.c2f_leader_name];
+        // Detect convs, for the merged launches of the latency path: all three levels must suit the shared kernel shape
+        bool det_ok = e->dtype == ZLY_DTYPE_BF16;
+        for (int l = 0; l < 3 && det_ok; ++l) {
+            const std::string L = std::to_string(l);
+            for (size_t i = 0; i < e->ops.size(); ++i) {
+                const Op& op = e->ops[i];
+                if (op.kind != OP_CONV) continue;
+                if (op.name.rfind("model.22.cv2." + L + ".0", 0) == 0) e->det_stem[l] = (int)i;
+                if (op.name == "model.22.cv2." + L + ".1") e->det_a[l] = (int)i;
+                if (op.name == "model.22.cv3." + L + ".1") e->det_b[l] = (int)i;
+            }
+            det_ok = e->det_stem[l] >= 0 && e->det_a[l] >= 0 && e->det_b[l] >= 0;
+            if (det_ok) {
+                const Op& S = e->ops[(size_t)e->det_stem[l]];
+                const Op& A = e->ops[(size_t)e->det_a[l]];
+                const Op& Bc = e->ops[(size_t)e->det_b[l]];
+                det_ok = S.ks == 3 && A.ks == 3 && Bc.ks == 3 && S.stride == 1 && S.in.C % 32 == 0 && A.in.C % 32 == 0 && Bc.in.C % 32 == 0 &&
+                         S.cout_pad % 48 == 0 && A.cout_pad % 32 == 0 && Bc.cout_pad % 32 == 0 && S.in2.buf < 0 && S.res.buf < 0 && A.res.buf < 0 && Bc.res.buf < 0;
+            }
+        }
+        if (!det_ok) e->det_stem[0] = -1;
     }
 
     // device allocations
@@ -637,12 +659,55 @@ static bool c2f_covered(zly_engine* e, const Op& op, int n)
     return op.c2f_leader >= 0 && !op.c2f_mode && c2f_active(e, e->ops[(size_t)op.c2f_leader], n) != nullptr;
 }
 
+// launch arguments of a conv op at batch n
+static ConvArgs make_conv_args(zly_engine* e, const Op& op, int n)
+{
+    const Buffer& ib = e->bufs[(size_t)op.in.buf];
+    const Buffer& ob = e->bufs[(size_t)op.out.buf];
+    ConvArgs a;
+    a.in = ib.ptr; a.in_cs = ib.C; a.in_co = op.in.co;
+    a.H = ib.H; a.W = ib.W; a.Cin = op.in.C;
+    a.wgt = (const char*)e->d_weights + op.w_off;
+    a.bias = (const float*)((const char*)e->d_weights + op.b_off);
+    a.out = ob.ptr; a.out_cs = ob.C; a.out_co = op.out.co;
+    a.Ho = ob.H; a.Wo = ob.W; a.Cout = op.cout; a.cout_pad = op.cout_pad;
+    if (op.res.buf >= 0) { const Buffer& rb = e->bufs[(size_t)op.res.buf]; a.res = rb.ptr; a.res_cs = rb.C; a.res_co = op.res.co; }
+    else { a.res = nullptr; a.res_cs = 0; a.res_co = 0; }
+    a.stride = op.stride; a.pad = op.ks / 2;
+    a.K = op.K; a.nk = op.nk; a.M = n * ob.H * ob.W; a.act = op.act; a.out_f32 = op.out_f32;
+    a.in2 = nullptr; a.in2_cs = 0; a.in2_co = 0; a.split_c = 0;
+    if (op.in2.buf >= 0) {
+        const Buffer& i2 = e->bufs[(size_t)op.in2.buf];
+        a.in2 = i2.ptr; a.in2_cs = i2.C; a.in2_co = op.in2.co; a.split_c = op.in.C;
+        a.H = ob.H; a.W = ob.W; a.Cin = op.in.C + op.in2.C;        // logical (full-size, concatenated) input
+    }
+    return a;
+}
+
+// Detect convs merged into two launches on the latency path (conv_igemm_multi_kernel): batch <= 4, no side streams in use
+static bool detect_merge_active(zly_engine* e, int n)
+{
+    if (e->dtype != ZLY_DTYPE_BF16 || e->det_stem[0] < 0 || n > 4 || lanes_active(e, n) || getenv("ZLY_NO_DET_MERGE") != nullptr) return false;
+    return true;
+}
+// role of op index i in the merged Detect launches: 0 none, 1 covered (no launch), 2 launches the three stems, 3 launches the six branch convs
+static int detect_merge_role(const zly_engine* e, int i)
+{
+    for (int l = 0; l < 3; ++l) {
+        if (i == e->det_stem[l]) return l == 2 ? 2 : 1;
+        if (i == e->det_a[l]) return l == 2 ? 3 : 1;
+        if (i == e->det_b[l]) return 1;
+    }
+    return 0;
+}
+
 // ops that launch nothing at this batch size (second conv of a fused pair; per-level tail ops when one launch covers all)
 static bool op_is_noop(zly_engine* e, const Op& op, int n)
 {
     if (op.kind == OP_PREPROCESS) return e->stem_fused;                          // detect paths: inside the stem kernel
     if (op.kind == OP_CONV && e->stem1 && op.name == "model.1") return true;     // detect paths: computed by stem_model1_kernel (booked on model.0)
     if (op.kind == OP_CONV && c2f_covered(e, op, n)) return true;
+    if (op.kind == OP_CONV && detect_merge_active(e, n) && detect_merge_role(e, (int)(&op - e->ops.data())) == 1) return true;
     if (op.kind == OP_CONV && op.pair == 2) return pair_active(e, op, n) != nullptr;
     if (op.kind == OP_HEAD && op.level != 2) return !lanes_active(e, n) || getenv("ZLY_NO_TAIL_SPLIT") != nullptr;
     return false;
@@ -657,6 +722,18 @@ static hipError_t run_op(zly_engine* e, const Op& op, int n, const uint8_t* d_sr
         const Buffer& ib = e->bufs[(size_t)op.in.buf];
         const Buffer& ob = e->bufs[(size_t)op.out.buf];
         if (c2f_covered(e, op, n)) return hipSuccess;               // computed by the fused C2f kernel launched at its leader
+        if (detect_merge_active(e, n)) {
+            const int role = detect_merge_role(e, (int)(&op - e->ops.data()));
+            if (role == 1) return hipSuccess;
+            if (role == 2 || role == 3) {
+                ConvArgsMulti m{};
+                for (int l = 0; l < 3; ++l) {
+                    if (role == 2) m.a[m.n++] = make_conv_args(e, e->ops[(size_t)e->det_stem[l]], n);
+                    else { m.a[m.n++] = make_conv_args(e, e->ops[(size_t)e->det_a[l]], n); m.a[m.n++] = make_conv_args(e, e->ops[(size_t)e->det_b[l]], n); }
+                }
+                return launch_conv_multi(m, role == 2 ? 3 : 2, s);
+            }
+        }
         if (const C2fPlan* pl = c2f_active(e, op, n)) {
             const Buffer& cb = e->bufs[(size_t)op.c2f_cat];
             const Buffer& xb = e->bufs[(size_t)op.c2f_x.buf];
@@ -695,23 +772,7 @@ static hipError_t run_op(zly_engine* e, const Op& op, int n, const uint8_t* d_sr
                 return launch_pair(op.pair_c, pa, *pl, s);
             }
         }
-        ConvArgs a;
-        a.in = ib.ptr; a.in_cs = ib.C; a.in_co = op.in.co;
-        a.H = ib.H; a.W = ib.W; a.Cin = op.in.C;
-        a.wgt = (const char*)e->d_weights + op.w_off;
-        a.bias = (const float*)((const char*)e->d_weights + op.b_off);
-        a.out = ob.ptr; a.out_cs = ob.C; a.out_co = op.out.co;
-        a.Ho = ob.H; a.Wo = ob.W; a.Cout = op.cout; a.cout_pad = op.cout_pad;
-        if (op.res.buf >= 0) { const Buffer& rb = e->bufs[(size_t)op.res.buf]; a.res = rb.ptr; a.res_cs = rb.C; a.res_co = op.res.co; }
-        else { a.res = nullptr; a.res_cs = 0; a.res_co = 0; }
-        a.stride = op.stride; a.pad = op.ks / 2;
-        a.K = op.K; a.nk = op.nk; a.M = n * ob.H * ob.W; a.act = op.act; a.out_f32 = op.out_f32;
-        a.in2 = nullptr; a.in2_cs = 0; a.in2_co = 0; a.split_c = 0;
-        if (op.in2.buf >= 0) {
-            const Buffer& i2 = e->bufs[(size_t)op.in2.buf];
-            a.in2 = i2.ptr; a.in2_cs = i2.C; a.in2_co = op.in2.co; a.split_c = op.in.C;
-            a.H = ob.H; a.W = ob.W; a.Cin = op.in.C + op.in2.C;        // logical (full-size, concatenated) input
-        }
+        ConvArgs a = make_conv_args(e, op, n);
         ConvLaunch cfg;
         conv_pick_config(e->dtype, op.ks, op.stride, a.Cin, op.cout_pad, n, ob.H, ob.W, &cfg,
                          a.in2 == nullptr && a.res == nullptr && a.act && !a.out_f32 && a.Cout % 32 == 0);
@@ -1797,6 +1858,11 @@ int32_t zly_op_kernel_name(zly_engine* e, int32_t i, int32_t n, char* out, size_
         if (i == 1 && e->stem1) { k = "stem_model1_kernel (preprocess+model.0+model.1)"; break; }
         if (i == 2 && e->stem1) { k = "(fused into the previous launch)"; break; }
         if (i == 1 && e->stem_fused) { k = "stem_fused_kernel"; break; }
+        if (detect_merge_active(e, n) && detect_merge_role(e, i)) {
+            const int role = detect_merge_role(e, i);
+            k = role == 1 ? "(in a merged Detect launch)" : role == 2 ? "conv_igemm_multi_kernel<CT=3> (the 3 Detect stems)" : "conv_igemm_multi_kernel<CT=2> (the 6 Detect branch convs)";
+            break;
+        }
         if (c2f_covered(e, op, n)) { k = "(fused into the C2f kernel at " + op.c2f_leader_name + ")"; break; }
         if (c2f_active(e, op, n)) {
             k = "c2f_kernel<C=" + std::to_string(op.c2f_c) + (op.c2f_mode == 3 ? ",cv1+bottleneck+cv2>" : op.c2f_mode == 1 ? ",cv1+bottleneck>" : ",bottleneck+cv2>");

@@ -143,7 +143,7 @@ __device__ __forceinline__ void epilogue_px_buf(const ConvArgs& a, __amdgpu_buff
 // The k-loop is software pipelined by hand: fragments of step s+1 are requested before the MFMAs of
 // step s issue (two named register sets, statically indexed).
 template <typename T, int MODE, int CT, int PT, int KSPLIT>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
+__device__ __forceinline__ void conv_igemm_body(const ConvArgs& a)
 {
     typedef typename Frag<T>::type F;
     constexpr int EPL = Frag<T>::EPL;
@@ -300,6 +300,39 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
         }
         epilogue_px<T, CT>(a, v, biasr, blockIdx.y * CT, kq, m);
     }
+}
+
+template <typename T, int MODE, int CT, int PT, int KSPLIT>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
+{
+    conv_igemm_body<T, MODE, CT, PT, KSPLIT>(a);
+}
+
+// Several independent 3x3 convs (same kernel shape: bf16, Cin % 32 == 0, CT channel tiles per wave, one 16-pixel tile per
+// workgroup, 4-way split-K) in ONE launch: blockIdx.z picks the conv.  The latency path (batch <= 4) is a chain of ~40 launches
+// of a few microseconds each; the Detect head's three pyramid levels are independent of each other, so their three stem convs go
+// in one launch and the six second convs of their box / class branches in another (9 launches -> 2).
+template <int CT>
+__global__ __launch_bounds__(256) void conv_igemm_multi_kernel(const ConvArgsMulti m)
+{
+    const ConvArgs& a = m.a[blockIdx.z];
+    if ((int)blockIdx.y * CT * 16 >= a.cout_pad || (int)blockIdx.x * 16 >= a.M) return;      // block-uniform: beyond this conv's extent
+    conv_igemm_body<bf16_t, 1, CT, 1, 4>(a);
+}
+
+hipError_t launch_conv_multi(const ConvArgsMulti& m, int ct, hipStream_t s)
+{
+    if (m.n < 1 || m.n > 6 || (ct != 2 && ct != 3)) return hipErrorInvalidValue;
+    int gx = 0, gy = 0;
+    for (int i = 0; i < m.n; ++i) {
+        const ConvArgs& a = m.a[i];
+        if (a.Cin % 32 || a.pad != 1 || a.in2 || a.out_f32 || a.cout_pad % (16 * ct)) return hipErrorInvalidValue;
+        gx = gx > (a.M + 15) / 16 ? gx : (a.M + 15) / 16;
+        gy = gy > a.cout_pad / (16 * ct) ? gy : a.cout_pad / (16 * ct);
+    }
+    if (ct == 2) hipLaunchKernelGGL(conv_igemm_multi_kernel<2>, dim3(gx, gy, m.n), dim3(256), 0, s, m);
+    else         hipLaunchKernelGGL(conv_igemm_multi_kernel<3>, dim3(gx, gy, m.n), dim3(256), 0, s, m);
+    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -41,6 +41,8 @@ struct ConvArgs {
 };
 
 struct ConvLaunch { int ks, ct, pt, fastk, ksplit, lds, stream, wres; };
+struct ConvArgsMulti { ConvArgs a[6]; int n; };       // independent convs of one launch (conv_igemm_multi_kernel)
+hipError_t launch_conv_multi(const ConvArgsMulti& m, int ct, hipStream_t s);
 
 // compute units the engine's streams may use: 256 (whole chip), or the size of its CU partition (engine.cpp: ZLY_CU_PART).  The
 // persistent grids of the conv kernels are sized from it (a persistent workgroup that waits for a slot runs a whole round alone).
