@@ -406,7 +406,7 @@ static int build_plan(zly_engine* e, std::string* err)
     const int a21 = pb.add_buffer("model.21", H32, W32, ch[4]);
 
     Op pre; pre.kind = OP_PREPROCESS; pre.name = "preprocess";
-    pre.bytes = (double)W * H * 3 + (double)W * H * 8 * e->esz;
+    pre.bytes = (double)W * H * 3 + (double)W * H * 3 * e->esz;          // algorithmic: u8 frame in, the 3-channel tensor out (stored as 8 channels)
     e->ops.push_back(pre);
 
     bool ok = true;
