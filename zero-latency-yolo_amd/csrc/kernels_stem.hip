@@ -145,7 +145,7 @@ int stem_tiles_x(int Wo) { return (Wo + STEM_TW - 1) / STEM_TW; }
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4s;
 #define STEM1_PITCH 40
-#define STEM1_MAXIT 9      // patch rows staged per thread (4 row groups: patches up to 36 rows, i.e. TH <= 8)
+#define STEM1_MAXIT 8      // input pixels staged per thread (8 waves: patches up to 4096 pixels)
 
 __device__ __forceinline__ int div_small_s(int q, float inv) { return (int)(((float)q + 0.5f) * inv); }   // exact for q < 2^20, divisor < 2^10
 
@@ -195,35 +195,23 @@ __global__ __launch_bounds__(NW * 64) void stem_model1_kernel(const Stem1Args a)
         if (!same) { sx = (int)((float)ix * scale_w); if (sx > d.w - 1) sx = d.w - 1; }
         const unsigned int col_off = col_ok ? (unsigned int)sx * 3u : 0u;
         const float kk = 1.0f / 255.0f;                          // bf16(u8 * (1/255.f)) == bf16(u8 / 255.f) for all 256 values (tests/test_model_spec.py)
-        // all of a thread's loads first (fully unrolled: STEM1_MAXIT rows per thread), then the conversions: one load per loop
-        // iteration would expose a memory round trip per row
-        unsigned int raw[STEM1_MAXIT];
-#pragma unroll
-        for (int k = 0; k < STEM1_MAXIT; ++k) {
-            const int r = rg + k * (NW / 2);
+        for (int r = rg; r < PH; r += NW / 2) {
             const int iy = iy0 + r;
-            raw[k] = 0x80000000u;                                 // bit 31: zero pixel (outside the model-sized image / beyond the patch)
-            if (r < PH && (unsigned)iy < (unsigned)a.st.th && col_ok) {
+            bf16x4 v = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+            if ((unsigned)iy < (unsigned)a.st.th) {              // wave-uniform
                 int sy = iy;
                 if (!same) { sy = (int)((float)iy * scale_h); if (sy > d.h - 1) sy = d.h - 1; }
-                const size_t off = (size_t)sy * d.w * 3 + col_off;
-                const uint8_t* q = src + off;
-                unsigned int px4;
-                if (off + 4 <= frame_bytes) __builtin_memcpy(&px4, q, 4);           // B | G<<8 | R<<16 | next B<<24 (unaligned global access is enabled on amdhsa)
-                else px4 = (unsigned int)q[0] | ((unsigned int)q[1] << 8) | ((unsigned int)q[2] << 16);
-                raw[k] = px4 & 0x00ffffffu;
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < STEM1_MAXIT; ++k) {
-            const int r = rg + k * (NW / 2);
-            if (r < PH && col < PW) {
-                bf16x4 v = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
-                if (!(raw[k] & 0x80000000u)) {
-                    v[0] = (bf16_t)((float)((raw[k] >> 16) & 0xffu) * kk); v[1] = (bf16_t)((float)((raw[k] >> 8) & 0xffu) * kk); v[2] = (bf16_t)((float)(raw[k] & 0xffu) * kk);
+                const size_t row_off = (size_t)sy * d.w * 3;
+                if (col_ok) {
+                    const size_t off = row_off + col_off;
+                    const uint8_t* q = src + off;
+                    unsigned int px4;
+                    if (off + 4 <= frame_bytes) __builtin_memcpy(&px4, q, 4);       // B | G<<8 | R<<16 | next B<<24 (unaligned global access is enabled on amdhsa)
+                    else px4 = (unsigned int)q[0] | ((unsigned int)q[1] << 8) | ((unsigned int)q[2] << 16);
+                    v[0] = (bf16_t)((float)((px4 >> 16) & 0xffu) * kk); v[1] = (bf16_t)((float)((px4 >> 8) & 0xffu) * kk); v[2] = (bf16_t)((float)(px4 & 0xffu) * kk);
                 }
-                patch[r * PW + col] = v;
             }
+            if (col < PW) patch[r * PW + col] = v;
         }
     }
     __syncthreads();
@@ -334,7 +322,7 @@ hipError_t launch_stem_model1(const Stem1Args& a, int n, hipStream_t s)
     if (a.st.Cout != 16 || a.TH < 1 || a.TW < 1 || a.out1_cs % 8 || a.out1_co % 8) return hipErrorInvalidValue;
     if (a.H1 * 2 != a.st.Ho || a.W1 * 2 != a.st.Wo) return hipErrorInvalidValue;      // even stem map: model.1 output = half of it
     const size_t lds = stem1_lds_bytes(a.TH, a.TW);
-    if (lds > 160 * 1024 || 4 * a.TW + 3 > 128 || 4 * a.TH + 3 > STEM1_MAXIT * (STEM1_NW / 2)) return hipErrorInvalidValue;     // thread layout of the staging loop
+    if (lds > 160 * 1024 || 4 * a.TW + 3 > 128) return hipErrorInvalidValue;        // one thread column per patch column
     hipLaunchKernelGGL(stem_model1_kernel<STEM1_NW>, dim3(a.tiles_x * a.tiles_y, n), dim3(STEM1_NW * 64), lds, s, a);
     return hipGetLastError();
 }
