@@ -182,36 +182,41 @@ __global__ __launch_bounds__(NW * 64) void stem_model1_kernel(const Stem1Args a)
     const bool same = d.w == a.st.tw && d.h == a.st.th;
     const size_t frame_bytes = (size_t)d.w * d.h * 3;
     const float invPW = 1.0f / (float)PW, invRW = 1.0f / (float)RW, invTW = 1.0f / (float)a.TW;
-    // Threads are laid out as 128 columns x (NW / 2) row groups: a wave sees ONE patch row, so the row's bounds test, source row
-    // (nearest-neighbour map) and base address are wave-uniform (scalar unit) and a thread's source column is computed once.  With
-    // the flat u = tid + k * 512 mapping this loop cost ~50 VALU instructions per pixel (divisions, 64-bit address arithmetic,
-    // per-pixel resize map) -- 40 % of the kernel's VALU work, which is what bounds it (970 VALU per wave, PMC).
-    {
-        const int col = tid & 127;
-        const int rg = __builtin_amdgcn_readfirstlane(tid >> 7);
-        const int ix = ix0 + col;
-        const bool col_ok = col < PW && (unsigned)ix < (unsigned)a.st.tw;
-        int sx = ix;
-        if (!same) { sx = (int)((float)ix * scale_w); if (sx > d.w - 1) sx = d.w - 1; }
-        const unsigned int col_off = col_ok ? (unsigned int)sx * 3u : 0u;
-        const float kk = 1.0f / 255.0f;                          // bf16(u8 * (1/255.f)) == bf16(u8 / 255.f) for all 256 values (tests/test_model_spec.py)
-        for (int r = rg; r < PH; r += NW / 2) {
-            const int iy = iy0 + r;
-            bf16x4 v = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
-            if ((unsigned)iy < (unsigned)a.st.th) {              // wave-uniform
-                int sy = iy;
-                if (!same) { sy = (int)((float)iy * scale_h); if (sy > d.h - 1) sy = d.h - 1; }
-                const size_t row_off = (size_t)sy * d.w * 3;
-                if (col_ok) {
-                    const size_t off = row_off + col_off;
-                    const uint8_t* q = src + off;
-                    unsigned int px4;
-                    if (off + 4 <= frame_bytes) __builtin_memcpy(&px4, q, 4);       // B | G<<8 | R<<16 | next B<<24 (unaligned global access is enabled on amdhsa)
-                    else px4 = (unsigned int)q[0] | ((unsigned int)q[1] << 8) | ((unsigned int)q[2] << 16);
-                    v[0] = (bf16_t)((float)((px4 >> 16) & 0xffu) * kk); v[1] = (bf16_t)((float)((px4 >> 8) & 0xffu) * kk); v[2] = (bf16_t)((float)(px4 & 0xffu) * kk);
+    // all of a thread's loads are issued before the first conversion (the loop below is fully unrolled: STEM1_MAXIT pixels per thread):
+    // with one load per loop iteration every iteration exposed a full memory round trip, ~6 us of the ~12 us a tile took
+    unsigned int raw[STEM1_MAXIT];
+#pragma unroll
+    for (int k = 0; k < STEM1_MAXIT; ++k) {
+        const int u = tid + k * NW * 64;
+        raw[k] = 0x80000000u;                                   // bit 31: pixel outside the model-sized image (or beyond the patch) -> zeros
+        if (u < PH * PW) {
+            const int py = div_small_s(u, invPW), px = u - py * PW;
+            const int iy = iy0 + py, ix = ix0 + px;
+            if ((unsigned)iy < (unsigned)a.st.th && (unsigned)ix < (unsigned)a.st.tw) {
+                int sy = iy, sx = ix;
+                if (!same) {
+                    sy = (int)((float)iy * scale_h); if (sy > d.h - 1) sy = d.h - 1;
+                    sx = (int)((float)ix * scale_w); if (sx > d.w - 1) sx = d.w - 1;
                 }
+                const size_t off = ((size_t)sy * d.w + sx) * 3;
+                const uint8_t* q = src + off;
+                unsigned int px4;
+                if (off + 4 <= frame_bytes) __builtin_memcpy(&px4, q, 4);        // B | G<<8 | R<<16 | next B<<24 (unaligned global access is enabled on amdhsa)
+                else px4 = (unsigned int)q[0] | ((unsigned int)q[1] << 8) | ((unsigned int)q[2] << 16);
+                raw[k] = px4 & 0x00ffffffu;
             }
-            if (col < PW) patch[r * PW + col] = v;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < STEM1_MAXIT; ++k) {
+        const int u = tid + k * NW * 64;
+        if (u < PH * PW) {
+            bf16x4 v = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+            if (!(raw[k] & 0x80000000u)) {
+                const float kk = 1.0f / 255.0f;                  // bf16(u8 * (1/255.f)) == bf16(u8 / 255.f) for all 256 values (tests/test_model_spec.py)
+                v[0] = (bf16_t)((float)((raw[k] >> 16) & 0xffu) * kk); v[1] = (bf16_t)((float)((raw[k] >> 8) & 0xffu) * kk); v[2] = (bf16_t)((float)(raw[k] & 0xffu) * kk);
+            }
+            patch[u] = v;
         }
     }
     __syncthreads();
@@ -322,7 +327,7 @@ hipError_t launch_stem_model1(const Stem1Args& a, int n, hipStream_t s)
     if (a.st.Cout != 16 || a.TH < 1 || a.TW < 1 || a.out1_cs % 8 || a.out1_co % 8) return hipErrorInvalidValue;
     if (a.H1 * 2 != a.st.Ho || a.W1 * 2 != a.st.Wo) return hipErrorInvalidValue;      // even stem map: model.1 output = half of it
     const size_t lds = stem1_lds_bytes(a.TH, a.TW);
-    if (lds > 160 * 1024 || 4 * a.TW + 3 > 128) return hipErrorInvalidValue;        // one thread column per patch column
+    if (lds > 160 * 1024 || (4 * a.TH + 3) * (4 * a.TW + 3) > STEM1_MAXIT * STEM1_NW * 64) return hipErrorInvalidValue;
     hipLaunchKernelGGL(stem_model1_kernel<STEM1_NW>, dim3(a.tiles_x * a.tiles_y, n), dim3(STEM1_NW * 64), lds, s, a);
     return hipGetLastError();
 }
