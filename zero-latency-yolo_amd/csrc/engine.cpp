@@ -1101,6 +1101,7 @@ struct Ingest {
     bool stop = false;
     std::thread dispatcher, completer;
     hipStream_t copy_stream = nullptr, d2h_stream = nullptr;
+    bool use_d2h_stream = false;
 };
 
 // One H2D and one D2H stream per device, shared by every engine of the process: each HIP stream beyond the hardware-queue limit (4 by default)
@@ -1137,6 +1138,7 @@ static void ingest_enqueue(zly_engine* e, Ingest* g, IngestSlot& sl)
     std::lock_guard<std::mutex> lk(e->mu);
     std::lock_guard<std::mutex> gl(g_enqueue_mu);
     const int n = sl.n_reserved;
+    hipStream_t out_stream = e->stream;
     auto body = [&]() -> int {
         HIP_TRY(hipSetDevice(e->dev), ZLY_ERR_SYSTEM);
         HIP_TRY(hipMemcpyAsync(sl.d_stage, sl.h_stage, sl.bytes_used, hipMemcpyHostToDevice, g->copy_stream), ZLY_ERR_INFERENCE);
@@ -1149,14 +1151,19 @@ static void ingest_enqueue(zly_engine* e, Ingest* g, IngestSlot& sl)
         rc = run_path(e, n, sl.d_stage, sl.d_slabs, (uint32_t)(sl.batch << 16), e->stream, true, (e->cfg.flags & ZLY_FLAG_ASYNC_NMS) != 0, &ns);
         e->ingest_active = false;
         if (rc != ZLY_OK) return rc;
-        HIP_TRY(hipEventRecord(sl.ev_done, ns), ZLY_ERR_INFERENCE);
-        HIP_TRY(hipStreamWaitEvent(g->d2h_stream, sl.ev_done, 0), ZLY_ERR_INFERENCE);
-        HIP_TRY(hipMemcpyAsync(sl.h_slabs, sl.d_slabs, slab_bytes_of(e) * (size_t)n, hipMemcpyDeviceToHost, g->d2h_stream), ZLY_ERR_INFERENCE);
+        // the slabs (n x 2.6 KB) go back on the stream the NMS ran on, right behind it: a download stream of its own would be the fifth
+        // stream of a three-engine process and share a hardware queue with a compute stream (ZLY_D2H_STREAM=1 restores it)
+        out_stream = g->use_d2h_stream ? g->d2h_stream : ns;
+        if (g->use_d2h_stream) {
+            HIP_TRY(hipEventRecord(sl.ev_done, ns), ZLY_ERR_INFERENCE);
+            HIP_TRY(hipStreamWaitEvent(g->d2h_stream, sl.ev_done, 0), ZLY_ERR_INFERENCE);
+        }
+        HIP_TRY(hipMemcpyAsync(sl.h_slabs, sl.d_slabs, slab_bytes_of(e) * (size_t)n, hipMemcpyDeviceToHost, out_stream), ZLY_ERR_INFERENCE);
         return ZLY_OK;
     };
     sl.rc = body();
     if (sl.rc != ZLY_OK) sl.err = g_last_error;
-    hipEventRecord(sl.ev_out, g->d2h_stream);          // also on failure: the completion thread must never wait forever
+    hipEventRecord(sl.ev_out, out_stream);             // also on failure: the completion thread must never wait forever
 }
 
 static void ingest_dispatch_loop(zly_engine* e, Ingest* g)
@@ -1234,8 +1241,9 @@ static int ingest_start(zly_engine* e)
     g->depth = std::max(1, std::min(S - 2, env_int("ZLY_INFLIGHT", 2)));
     g->slots.resize((size_t)S);
     const int dv = e->dev & 15;
+    g->use_d2h_stream = env_int("ZLY_D2H_STREAM", 0) != 0;
     bool ok = (g_h2d_stream[dv] || hipStreamCreateWithFlags(&g_h2d_stream[dv], hipStreamNonBlocking) == hipSuccess) &&
-              (g_d2h_stream[dv] || hipStreamCreateWithFlags(&g_d2h_stream[dv], hipStreamNonBlocking) == hipSuccess);
+              (!g->use_d2h_stream || g_d2h_stream[dv] || hipStreamCreateWithFlags(&g_d2h_stream[dv], hipStreamNonBlocking) == hipSuccess);
     g->copy_stream = g_h2d_stream[dv]; g->d2h_stream = g_d2h_stream[dv];
     const size_t sb = slab_bytes_of(e) * (size_t)e->cfg.max_batch;
     for (IngestSlot& sl : g->slots) {
