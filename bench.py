@@ -193,7 +193,7 @@ def host_to_host(threads, seconds=4.0, max_batch=64, engines=1):
     one host copy into the pinned ring, the PCIe upload (overlapped with the previous batch's compute) and the slab download."""
     import subprocess
     exe = os.path.join(ROOT, "zero-latency-yolo_amd", "_build", "zly_h2h_bench")
-    out = {"threads": threads, "pcie_ceiling_frames_per_sec": round(63e9 / 519168, 0),
+    out = {"threads": threads, "engines": engines, "pcie_ceiling_frames_per_sec": round(63e9 / 519168, 0),
            "note": "pageable host frames -> zly_submit (copy into the pinned ring on the submitting thread) -> H2D on a copy stream beside "
                    "the previous batch's compute -> path -> slab D2H -> zly_wait; 63 GB/s PCIe Gen5 x16 / 519168 B = 121 k frames/s ceiling"}
     for mode in ("cabi", "plugin"):
@@ -416,7 +416,7 @@ def run():
                                                                   "kept_max": int(max(int(h["n_kept"]) for h in hdrs))}
     if rank == 0 and world == 1 and not a.no_extras and os.environ.get("ZLY_BENCH_NO_H2H") != "1":
         log("host-to-host throughput leg (native driver, 2 x ~5 s)")
-        h2h = host_to_host(max(8, min(12, host_cores() - 3)), engines=n_eng)
+        h2h = host_to_host(max(8, min(12, host_cores() - 3)), engines=2)      # 2 engines + the shared upload stream = one hardware queue per stream
         result["throughput_host_to_host"] = h2h
         if "frames_per_sec" in h2h.get("cabi", {}):
             result["throughput_host_to_host"]["frac_of_device_resident"] = round(h2h["cabi"]["frames_per_sec"] / value, 3)
