@@ -6,11 +6,14 @@ YOLOv8n 416x416, batch 1 / 64, 1-8 MI355X).
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the hot path (preprocess -> YOLOv8n forward -> decode -> NMS -> result slab)
-over one batch of synthetic frames that are already resident in HBM.  BASELINE.json's metric is
+over one batch of synthetic frames that are already resident in HBM.  By default the steps alternate over three engine
+instances per GPU (--engines 3, ZLY_FLAG_SINGLE_CHAIN): each step is one chain of launches on its engine's stream and the chains
+of consecutive steps overlap on the device; --engines 1 runs one engine with Detect side streams and deferred NMS.  BASELINE.json's metric is
 "frames/sec + p50 detect latency, YOLOv8n 416x416 batch 1/64": the headline `value` is frames/s on the
 batch-64 throughput configuration (configs[2]); the batch-1 latency configuration (configs[1]: frames/s
 with resident frames, and the host-to-host p50 detect latency through zly_detect) is measured in the
-same run and reported in the same JSON line as `latency_path_b1`.  With N > 1 each rank (one process per GPU) detects its own frames -- frames are sharded
+same run and reported in the same JSON line as `latency_path_b1`; `throughput_host_to_host` is the same path fed
+from host memory by >= 8 threads through zly_submit / zly_wait and through the plugin (native driver, child process).  With N > 1 each rank (one process per GPU) detects its own frames -- frames are sharded
 one-per-GPU, no data-path collective -- and the per-frame result slabs are all-gathered over
 RCCL/xGMI, overlapped with the next step (weak scaling: per-GPU work is fixed).
 

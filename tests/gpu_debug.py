@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in ("zero-latency-yolo_amd", "zero-latency-yolo_amd/tools", "oracle", "tests"):
     sys.path.insert(0, os.path.join(ROOT, p))
 import zly, zly_model as zm, yolov8_ref
-from oracle_lib import Oracle
+from oracle_lib import Oracle, det_fields_equal
 
 def main():
     mode = sys.argv[1] if len(sys.argv) > 1 else "fp32"
@@ -43,5 +43,5 @@ def main():
         odet = orc.postprocess(want[i], 416, 416)
         own = orc.postprocess(eng.head_tensor(0), 416, 416)
         print(f"frame {i}: gpu n={n} oracle(ref head) n={len(odet)} oracle(gpu head) n={len(own)} "
-              f"bitexact-vs-own-head={dets[['x','y','w','h','confidence','class_id']].tobytes() == own[['x','y','w','h','confidence','class_id']].tobytes()}")
+              f"bitexact-vs-own-head={det_fields_equal(dets, own[:512])}")
 main()
