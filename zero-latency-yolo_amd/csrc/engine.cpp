@@ -1673,8 +1673,12 @@ int32_t zly_read_slabs(zly_engine* e, int32_t n, void* host_slabs)
     if (!host_slabs || n < 1 || n > e->cfg.max_batch) return fail(ZLY_ERR_INVALID_ARGUMENT, "bad argument");
     std::lock_guard<std::mutex> lk(e->mu);
     HIP_TRY(hipSetDevice(e->dev), ZLY_ERR_SYSTEM);
-    { int rcj = join_nms(e, e->stream); if (rcj != ZLY_OK) return rcj; }
-    HIP_TRY(hipMemcpyAsync(host_slabs, e->d_slabs, slab_bytes_of(e) * (size_t)n, hipMemcpyDeviceToHost, e->stream), ZLY_ERR_INFERENCE);
+    {
+        std::lock_guard<std::mutex> gl(g_enqueue_mu);
+        int rcj = join_nms(e, e->stream);
+        if (rcj != ZLY_OK) return rcj;
+        HIP_TRY(hipMemcpyAsync(host_slabs, e->d_slabs, slab_bytes_of(e) * (size_t)n, hipMemcpyDeviceToHost, e->stream), ZLY_ERR_INFERENCE);
+    }
     HIP_TRY(hipStreamSynchronize(e->stream), ZLY_ERR_INFERENCE);
     return ZLY_OK;
 }
@@ -1686,6 +1690,7 @@ int32_t zly_preprocess(zly_engine* e, const uint8_t* bgr, size_t nbytes, int32_t
     if (!bgr || w <= 0 || h <= 0 || nbytes != (size_t)w * (size_t)h * 3u)
         return fail(ZLY_ERR_INVALID_INPUT, "Invalid image data size: expected " + std::to_string((size_t)(w > 0 ? w : 0) * (size_t)(h > 0 ? h : 0) * 3u) + ", got " + std::to_string(nbytes));
     std::lock_guard<std::mutex> lk(e->mu);
+    std::lock_guard<std::mutex> gl(g_enqueue_mu);         // parity / debug entry point: allocations and copies, never beside another engine's capture
     HIP_TRY(hipSetDevice(e->dev), ZLY_ERR_SYSTEM);
     int rc = ensure_stage(e, nbytes);
     if (rc != ZLY_OK) return rc;
@@ -1735,6 +1740,7 @@ int32_t zly_head_tensor(zly_engine* e, int32_t idx, float* head_out)
     if (!e) return fail(ZLY_ERR_NOT_INITIALIZED, "Engine not running");
     if (!head_out || idx < 0 || idx >= e->cfg.max_batch) return fail(ZLY_ERR_INVALID_ARGUMENT, "bad argument");
     std::lock_guard<std::mutex> lk(e->mu);
+    std::lock_guard<std::mutex> gl(g_enqueue_mu);         // parity / debug entry point: allocations and copies, never beside another engine's capture
     HIP_TRY(hipSetDevice(e->dev), ZLY_ERR_SYSTEM);
     if (e->cfg.flags & ZLY_FLAG_NO_HEAD_TENSOR) return fail(ZLY_ERR_INVALID_ARGUMENT, "engine was created with ZLY_FLAG_NO_HEAD_TENSOR: the head tensor is not materialised");
     const size_t per = (4 + (size_t)e->nc) * e->N;
@@ -1750,6 +1756,7 @@ int32_t zly_postprocess(zly_engine* e, const float* head, int32_t num_classes, i
     if (!head || !out || !n_out || num_classes < 1 || num_classes > 1024 || num_boxes < 0 || cap < 1 || img_w <= 0 || img_h <= 0)
         return fail(ZLY_ERR_INVALID_ARGUMENT, "bad argument");
     std::lock_guard<std::mutex> lk(e->mu);
+    std::lock_guard<std::mutex> gl(g_enqueue_mu);         // parity / debug entry point: allocations and copies, never beside another engine's capture
     HIP_TRY(hipSetDevice(e->dev), ZLY_ERR_SYSTEM);
     *n_out = 0;
     if (n_candidates) *n_candidates = 0;
@@ -1793,6 +1800,7 @@ int32_t zly_debug_tap(zly_engine* e, const char* name, int32_t idx, float* out, 
     if (!e) return fail(ZLY_ERR_NOT_INITIALIZED, "Engine not running");
     if (!name || !out || idx < 0 || idx >= e->cfg.max_batch) return fail(ZLY_ERR_INVALID_ARGUMENT, "bad argument");
     std::lock_guard<std::mutex> lk(e->mu);
+    std::lock_guard<std::mutex> gl(g_enqueue_mu);         // parity / debug entry point: allocations and copies, never beside another engine's capture
     HIP_TRY(hipSetDevice(e->dev), ZLY_ERR_SYSTEM);
     int buf = -1, co = 0, C = 0;
     bool f32 = false;
