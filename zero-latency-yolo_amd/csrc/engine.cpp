@@ -1646,6 +1646,7 @@ int32_t zly_join(zly_engine* e, void* stream, int32_t lag)
     if (!e) return fail(ZLY_ERR_NOT_INITIALIZED, "Engine not running");
     if (lag < 0) return fail(ZLY_ERR_INVALID_ARGUMENT, "lag must be >= 0");
     std::lock_guard<std::mutex> lk(e->mu);
+    std::lock_guard<std::mutex> gl(g_enqueue_mu);
     HIP_TRY(hipSetDevice(e->dev), ZLY_ERR_SYSTEM);
     hipStream_t s = stream ? (hipStream_t)stream : e->stream;
     // every call but the last `lag`: calls are stream-ordered among themselves, so waiting for call (last - lag) covers all earlier ones
