@@ -15,6 +15,7 @@
 //      fragment (two taps x 4 channels);
 //   4. bias + SiLU, 8-byte NHWC stores: the 4 lanes of a pixel write its 32 bytes contiguously.
 #include "zly_internal.h"
+#include <stdlib.h>
 
 namespace zly {
 
@@ -314,6 +315,8 @@ void stem1_plan(int H1, int W1, int* th, int* tw)
     *tw = 26;
     for (int c = 26; c >= 13; --c)
         if (W1 % c == 0) { *tw = c; break; }
+    if (const char* v = getenv("ZLY_STEM1_TW")) { if (atoi(v) >= 8 && atoi(v) <= 26) *tw = atoi(v); }      // tuning aids
+    if (const char* v = getenv("ZLY_STEM1_TH")) { if (atoi(v) >= 2 && atoi(v) <= 8) *th = atoi(v); }
     (void)H1;
 }
 
