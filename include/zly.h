@@ -30,7 +30,8 @@
  *   return codes               zero_latency::ErrorCode             src/common/result.h:14-48
  *
  * Threading: one engine handle may be used from several host threads; calls on one handle are
- * serialised internally (the reference serialises Session::Run the same way, onnx_engine.cpp:577).
+ * serialised internally (the reference serialises Session::Run the same way, onnx_engine.cpp:577), and the enqueue
+ * sections of ALL engines of a process are serialised among themselves (~0.1 ms each; stream capture is process-global in HIP).
  * Ownership: the caller owns every host buffer for the duration of the call; the engine owns all
  * device and pinned memory.  There is NO CPU fallback: without a usable HIP device zly_create
  * fails with ZLY_ERR_SYSTEM.
@@ -63,7 +64,7 @@ extern "C" {
                                    "model.22.cv2.L.2" / "model.22.cv3.L.2"); off in production */
 #define ZLY_FLAG_NO_HEAD_TENSOR 4 /* production: the Detect kernel decodes in registers and does not write the fp32 [4+nc][N] head tensor
                                    (the reference's ORT output, 1.2 MB per frame); zly_head_tensor / zly_forward then return 2 */
-#define ZLY_FLAG_ASYNC_NMS   8   /* zly_detect_device only: NMS of a call runs on an engine-owned stream beside the first kernels of the
+#define ZLY_FLAG_ASYNC_NMS   8   /* zly_detect_device and the pipelined zly_submit path (batches >= 16): NMS of a call runs on an engine-owned stream beside the first kernels of the
                                    NEXT call (it is 64 latency-bound workgroups).  The slabs of a call are then complete after zly_join
                                    (stream order) or zly_sync / zly_read_slabs (host), whichever comes first. */
 #define ZLY_FLAG_SINGLE_CHAIN 16 /* no side streams: the whole step is one chain of launches on one stream.  For SEVERAL engines per GPU fed alternate

@@ -1410,7 +1410,7 @@ static int ingest_wait(zly_engine* e, uint64_t ticket, zly_det* out, int32_t cap
 extern "C" {
 
 const char* zly_last_error(void) { return g_last_error.c_str(); }
-const char* zly_version(void) { return "zly-hip 0.1 (gfx950)"; }
+const char* zly_version(void) { return "zly-hip 0.2 (gfx950)"; }
 
 void zly_default_config(zly_config* c)
 {
