@@ -15,7 +15,6 @@
 //      fragment (two taps x 4 channels);
 //   4. bias + SiLU, 8-byte NHWC stores: the 4 lanes of a pixel write its 32 bytes contiguously.
 #include "zly_internal.h"
-#include <algorithm>
 #include <stdlib.h>
 
 namespace zly {
@@ -164,163 +163,141 @@ __global__ __launch_bounds__(NW * 64) void stem_model1_kernel(const Stem1Args a)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int p = lane & 15, kq = lane >> 4;
+    const int f = blockIdx.y;
+    const int ty = blockIdx.x / a.tiles_x, tx = blockIdx.x - ty * a.tiles_x;
+    const int oy1 = ty * a.TH, ox1 = tx * a.TW;              // model.1 output tile origin
+    const int sy0 = 2 * oy1 - 1, sx0 = 2 * ox1 - 1;          // stem region origin (stem output coordinates)
+    const int iy0 = 2 * sy0 - 1, ix0 = 2 * sx0 - 1;          // input patch origin (model-input pixel coordinates)
 
     for (int u = tid; u < 2 * 9 * 512 / 16; u += NW * 64)
         *reinterpret_cast<u32x4s*>(lw + (size_t)u * 16) = *reinterpret_cast<const u32x4s*>(static_cast<const unsigned char*>(a.w1) + (size_t)u * 16);
 
     const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(static_cast<const bf16_t*>(a.st.wgt) + lane * 8);
     const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(static_cast<const bf16_t*>(a.st.wgt) + 512 + lane * 8);
-    const float invPW = 1.0f / (float)PW, invRW = 1.0f / (float)RW, invTW = 1.0f / (float)a.TW;
-    const int tiles_per_frame = a.tiles_x * a.tiles_y;
 
-    // taps of this lane in the stem conv: k-step s, fragment half j -> tap = s*8 + kq*2 + j (taps >= 9 have zero weights: read any valid pixel)
+    // ---- 1. input patch ------------------------------------------------------------------------------------------
+    const FrameDesc d = a.st.desc[f];
+    const float scale_w = (float)d.w / (float)a.st.tw;
+    const float scale_h = (float)d.h / (float)a.st.th;
+    const uint8_t* src = a.st.src + d.src_off;
+    const bool same = d.w == a.st.tw && d.h == a.st.th;
+    const size_t frame_bytes = (size_t)d.w * d.h * 3;
+    const float invPW = 1.0f / (float)PW, invRW = 1.0f / (float)RW, invTW = 1.0f / (float)a.TW;
+    // all of a thread's loads are issued before the first conversion (the loop below is fully unrolled: STEM1_MAXIT pixels per thread):
+    // with one load per loop iteration every iteration exposed a full memory round trip, ~6 us of the ~12 us a tile took
+    unsigned int raw[STEM1_MAXIT];
+#pragma unroll
+    for (int k = 0; k < STEM1_MAXIT; ++k) {
+        const int u = tid + k * NW * 64;
+        raw[k] = 0x80000000u;                                   // bit 31: pixel outside the model-sized image (or beyond the patch) -> zeros
+        if (u < PH * PW) {
+            const int py = div_small_s(u, invPW), px = u - py * PW;
+            const int iy = iy0 + py, ix = ix0 + px;
+            if ((unsigned)iy < (unsigned)a.st.th && (unsigned)ix < (unsigned)a.st.tw) {
+                int sy = iy, sx = ix;
+                if (!same) {
+                    sy = (int)((float)iy * scale_h); if (sy > d.h - 1) sy = d.h - 1;
+                    sx = (int)((float)ix * scale_w); if (sx > d.w - 1) sx = d.w - 1;
+                }
+                const size_t off = ((size_t)sy * d.w + sx) * 3;
+                const uint8_t* q = src + off;
+                unsigned int px4;
+                if (off + 4 <= frame_bytes) __builtin_memcpy(&px4, q, 4);        // B | G<<8 | R<<16 | next B<<24 (unaligned global access is enabled on amdhsa)
+                else px4 = (unsigned int)q[0] | ((unsigned int)q[1] << 8) | ((unsigned int)q[2] << 16);
+                raw[k] = px4 & 0x00ffffffu;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < STEM1_MAXIT; ++k) {
+        const int u = tid + k * NW * 64;
+        if (u < PH * PW) {
+            bf16x4 v = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+            if (!(raw[k] & 0x80000000u)) {
+                const float kk = 1.0f / 255.0f;                  // bf16(u8 * (1/255.f)) == bf16(u8 / 255.f) for all 256 values (tests/test_model_spec.py)
+                v[0] = (bf16_t)((float)((raw[k] >> 16) & 0xffu) * kk); v[1] = (bf16_t)((float)((raw[k] >> 8) & 0xffu) * kk); v[2] = (bf16_t)((float)(raw[k] & 0xffu) * kk);
+            }
+            patch[u] = v;
+        }
+    }
+    __syncthreads();
+
+    // ---- 2. stem conv over the region -> LDS map ---------------------------------------------------------------------
     int toff[2][2];
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int tap = s * 8 + kq * 2 + j;
+            const int tap = s * 8 + kq * 2 + j;                 // taps >= 9 have zero weights: read any valid pixel
             const int ky = tap < 9 ? tap / 3 : 0, kx = tap < 9 ? tap - (tap / 3) * 3 : 0;
             toff[s][j] = ky * PW + kx;
         }
     const f32x4 bias0 = *reinterpret_cast<const f32x4*>(a.st.bias + kq * 4);
-    const f32x4 b1lo = *reinterpret_cast<const f32x4*>(a.b1 + kq * 8), b1hi = *reinterpret_cast<const f32x4*>(a.b1 + kq * 8 + 4);
-    const unsigned char* wl = lw + lane * 8;
     const int NR = RH * RW, ntR = (NR + 15) >> 4;
+    for (int t = wave; t < ntR; t += NW) {
+        const int q = t * 16 + p;
+        const int qc = min(q, NR - 1);
+        const int ry = div_small_s(qc, invRW), rx = qc - ry * RW;
+        const int base = (2 * ry) * PW + 2 * rx;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const bf16x4 lo = patch[base + toff[s][0]];
+            const bf16x4 hi = patch[base + toff[s][1]];
+            bf16x8 af;
+            af[0] = lo[0]; af[1] = lo[1]; af[2] = lo[2]; af[3] = lo[3];
+            af[4] = hi[0]; af[5] = hi[1]; af[6] = hi[2]; af[7] = hi[3];
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(s == 0 ? w0 : w1, af, acc, 0, 0, 0);
+        }
+        const int sy = sy0 + ry, sx = sx0 + rx;
+        const bool inmap = (unsigned)sy < (unsigned)a.st.Ho && (unsigned)sx < (unsigned)a.st.Wo;
+        f32x4 v = acc + bias0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = inmap ? v[r] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v[r] * -1.442695041f)) : 0.0f;
+        bf16x4 o;
+        o[0] = (bf16_t)v[0]; o[1] = (bf16_t)v[1]; o[2] = (bf16_t)v[2]; o[3] = (bf16_t)v[3];
+        if (q < NR) {
+            *reinterpret_cast<bf16x4*>(smap + (size_t)q * STEM1_PITCH + kq * 8) = o;
+            // debug taps: the stem pixels this tile owns (rows / columns 1 .. 2TH / 2TW of the region) also go to the model.0 tensor
+            if (a.dump && inmap && ry >= 1 && rx >= 1)
+                *reinterpret_cast<bf16x4*>(static_cast<bf16_t*>(a.st.out) + (((size_t)f * a.st.Ho + sy) * a.st.Wo + sx) * a.st.out_cs + a.st.out_co + kq * 4) = o;
+        }
+    }
+    __syncthreads();
+
+    // ---- 3. model.1 (3x3 s2, 16 -> 32) from the LDS map --------------------------------------------------------------------
+    f32x4 b1lo = *reinterpret_cast<const f32x4*>(a.b1 + kq * 8), b1hi = *reinterpret_cast<const f32x4*>(a.b1 + kq * 8 + 4);
     const int NO = a.TH * a.TW, ntO = (NO + 15) >> 4;
-
-    // The workgroup is persistent over tiles (grid = the resident workgroups): the raw pixels of the NEXT tile are requested before
-    // the two conv phases of the current one and converted after them.  Measured by ablation at batch 64: the loads alone cost 22 us
-    // of the kernel's 74 (4-byte loads at a 3-byte stride), the two conv phases 29 us, launching 3328 one-tile workgroups 16 us.
-    unsigned int raw[STEM1_MAXIT];
-    auto load_raw = [&](int tile) {
-        const int f = tile / tiles_per_frame;
-        const int r = tile - f * tiles_per_frame;
-        const int ty = r / a.tiles_x, tx = r - ty * a.tiles_x;
-        const int iy0 = 4 * (ty * a.TH) - 3, ix0 = 4 * (tx * a.TW) - 3;       // input patch origin (model-input pixel coordinates)
-        const FrameDesc d = a.st.desc[f];
-        const float scale_w = (float)d.w / (float)a.st.tw;
-        const float scale_h = (float)d.h / (float)a.st.th;
-        const uint8_t* src = a.st.src + d.src_off;
-        const bool same = d.w == a.st.tw && d.h == a.st.th;
-        const size_t frame_bytes = (size_t)d.w * d.h * 3;
+    const unsigned char* wl = lw + lane * 8;
+    for (int t = wave; t < ntO; t += NW) {
+        const int q = t * 16 + p;
+        const int qc = min(q, NO - 1);
+        const int oy = div_small_s(qc, invTW), ox = qc - oy * a.TW;
+        const unsigned char* row0 = smap + ((size_t)(2 * oy) * RW + 2 * ox) * STEM1_PITCH + kq * 8;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < STEM1_MAXIT; ++k) {
-            const int u = tid + k * NW * 64;
-            raw[k] = 0x80000000u;                               // bit 31: pixel outside the model-sized image (or beyond the patch) -> zeros
-            if (u < PH * PW) {
-                const int py = div_small_s(u, invPW), px = u - py * PW;
-                const int iy = iy0 + py, ix = ix0 + px;
-                if ((unsigned)iy < (unsigned)a.st.th && (unsigned)ix < (unsigned)a.st.tw) {
-                    int sy = iy, sx = ix;
-                    if (!same) {                                // the reference's nearest-neighbour map (onnx_engine.cpp:673-685)
-                        sy = (int)((float)iy * scale_h); if (sy > d.h - 1) sy = d.h - 1;
-                        sx = (int)((float)ix * scale_w); if (sx > d.w - 1) sx = d.w - 1;
-                    }
-                    const size_t off = ((size_t)sy * d.w + sx) * 3;
-                    const uint8_t* q = src + off;
-                    unsigned int px4;
-                    if (off + 4 <= frame_bytes) __builtin_memcpy(&px4, q, 4);    // B | G<<8 | R<<16 | next B<<24 (unaligned global access is enabled on amdhsa)
-                    else px4 = (unsigned int)q[0] | ((unsigned int)q[1] << 8) | ((unsigned int)q[2] << 16);
-                    raw[k] = px4 & 0x00ffffffu;
-                }
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const s16x4 x = *reinterpret_cast<const s16x4*>(row0 + ((size_t)ky * RW + kx) * STEM1_PITCH);
+                const s16x4 wa = *reinterpret_cast<const s16x4*>(wl + (0 * 9 + ky * 3 + kx) * 512);
+                const s16x4 wb = *reinterpret_cast<const s16x4*>(wl + (1 * 9 + ky * 3 + kx) * 512);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wa, x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wb, x, acc1, 0, 0, 0);
             }
+        const int gy = oy1 + oy, gx = ox1 + ox;
+        if (q < NO && gy < a.H1 && gx < a.W1) {
+            f32x4 lo = acc0 + b1lo, hi = acc1 + b1hi;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                lo[r] = lo[r] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(lo[r] * -1.442695041f));
+                hi[r] = hi[r] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(hi[r] * -1.442695041f));
+            }
+            bf16x8 o;
+            o[0] = (bf16_t)lo[0]; o[1] = (bf16_t)lo[1]; o[2] = (bf16_t)lo[2]; o[3] = (bf16_t)lo[3];
+            o[4] = (bf16_t)hi[0]; o[5] = (bf16_t)hi[1]; o[6] = (bf16_t)hi[2]; o[7] = (bf16_t)hi[3];
+            *reinterpret_cast<bf16x8*>(static_cast<bf16_t*>(a.out1) + (((size_t)f * a.H1 + gy) * a.W1 + gx) * a.out1_cs + a.out1_co + kq * 8) = o;
         }
-    };
-
-    int tile = blockIdx.x;
-    if (tile >= a.total_tiles) return;
-    load_raw(tile);
-    while (true) {
-        const int f = tile / tiles_per_frame;
-        const int rr = tile - f * tiles_per_frame;
-        const int ty = rr / a.tiles_x, tx = rr - ty * a.tiles_x;
-        const int oy1 = ty * a.TH, ox1 = tx * a.TW;          // model.1 output tile origin
-        const int sy0 = 2 * oy1 - 1, sx0 = 2 * ox1 - 1;      // stem region origin (stem output coordinates)
-
-        // ---- 1. raw pixels -> {R,G,B,0} bf16 patch in LDS -------------------------------------------------------------
-#pragma unroll
-        for (int k = 0; k < STEM1_MAXIT; ++k) {
-            const int u = tid + k * NW * 64;
-            if (u < PH * PW) {
-                bf16x4 v = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
-                if (!(raw[k] & 0x80000000u)) {
-                    const float kk = 1.0f / 255.0f;              // bf16(u8 * (1/255.f)) == bf16(u8 / 255.f) for all 256 values (tests/test_model_spec.py)
-                    v[0] = (bf16_t)((float)((raw[k] >> 16) & 0xffu) * kk); v[1] = (bf16_t)((float)((raw[k] >> 8) & 0xffu) * kk); v[2] = (bf16_t)((float)(raw[k] & 0xffu) * kk);
-                }
-                patch[u] = v;
-            }
-        }
-        __syncthreads();                                     // patch (and, first time, the weights) visible
-        const int tnext = tile + gridDim.x;
-        if (tnext < a.total_tiles) load_raw(tnext);          // in flight during the two conv phases
-
-        // ---- 2. stem conv over the region -> LDS map ---------------------------------------------------------------------
-        for (int t = wave; t < ntR; t += NW) {
-            const int q = t * 16 + p;
-            const int qc = min(q, NR - 1);
-            const int ry = div_small_s(qc, invRW), rx = qc - ry * RW;
-            const int base = (2 * ry) * PW + 2 * rx;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const bf16x4 lo = patch[base + toff[s][0]];
-                const bf16x4 hi = patch[base + toff[s][1]];
-                bf16x8 af;
-                af[0] = lo[0]; af[1] = lo[1]; af[2] = lo[2]; af[3] = lo[3];
-                af[4] = hi[0]; af[5] = hi[1]; af[6] = hi[2]; af[7] = hi[3];
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(s == 0 ? w0 : w1, af, acc, 0, 0, 0);
-            }
-            const int sy = sy0 + ry, sx = sx0 + rx;
-            const bool inmap = (unsigned)sy < (unsigned)a.st.Ho && (unsigned)sx < (unsigned)a.st.Wo;
-            f32x4 v = acc + bias0;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = inmap ? v[r] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v[r] * -1.442695041f)) : 0.0f;
-            bf16x4 o;
-            o[0] = (bf16_t)v[0]; o[1] = (bf16_t)v[1]; o[2] = (bf16_t)v[2]; o[3] = (bf16_t)v[3];
-            if (q < NR) {
-                *reinterpret_cast<bf16x4*>(smap + (size_t)q * STEM1_PITCH + kq * 8) = o;
-                // debug taps: the stem pixels this tile owns (rows / columns 1 .. 2TH / 2TW of the region) also go to the model.0 tensor
-                if (a.dump && inmap && ry >= 1 && rx >= 1)
-                    *reinterpret_cast<bf16x4*>(static_cast<bf16_t*>(a.st.out) + (((size_t)f * a.st.Ho + sy) * a.st.Wo + sx) * a.st.out_cs + a.st.out_co + kq * 4) = o;
-            }
-        }
-        __syncthreads();
-
-        // ---- 3. model.1 (3x3 s2, 16 -> 32) from the LDS map --------------------------------------------------------------------
-        for (int t = wave; t < ntO; t += NW) {
-            const int q = t * 16 + p;
-            const int qc = min(q, NO - 1);
-            const int oy = div_small_s(qc, invTW), ox = qc - oy * a.TW;
-            const unsigned char* row0 = smap + ((size_t)(2 * oy) * RW + 2 * ox) * STEM1_PITCH + kq * 8;
-            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const s16x4 x = *reinterpret_cast<const s16x4*>(row0 + ((size_t)ky * RW + kx) * STEM1_PITCH);
-                    const s16x4 wa = *reinterpret_cast<const s16x4*>(wl + (0 * 9 + ky * 3 + kx) * 512);
-                    const s16x4 wb = *reinterpret_cast<const s16x4*>(wl + (1 * 9 + ky * 3 + kx) * 512);
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wa, x, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wb, x, acc1, 0, 0, 0);
-                }
-            const int gy = oy1 + oy, gx = ox1 + ox;
-            if (q < NO && gy < a.H1 && gx < a.W1) {
-                f32x4 lo = acc0 + b1lo, hi = acc1 + b1hi;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    lo[r] = lo[r] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(lo[r] * -1.442695041f));
-                    hi[r] = hi[r] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(hi[r] * -1.442695041f));
-                }
-                bf16x8 o;
-                o[0] = (bf16_t)lo[0]; o[1] = (bf16_t)lo[1]; o[2] = (bf16_t)lo[2]; o[3] = (bf16_t)lo[3];
-                o[4] = (bf16_t)hi[0]; o[5] = (bf16_t)hi[1]; o[6] = (bf16_t)hi[2]; o[7] = (bf16_t)hi[3];
-                *reinterpret_cast<bf16x8*>(static_cast<bf16_t*>(a.out1) + (((size_t)f * a.H1 + gy) * a.W1 + gx) * a.out1_cs + a.out1_co + kq * 8) = o;
-            }
-        }
-        if (tnext >= a.total_tiles) break;
-        tile = tnext;
-        __syncthreads();                                     // all reads of the patch / map done before they are overwritten
     }
 }
 
@@ -354,11 +331,7 @@ hipError_t launch_stem_model1(const Stem1Args& a, int n, hipStream_t s)
     if (a.H1 * 2 != a.st.Ho || a.W1 * 2 != a.st.Wo) return hipErrorInvalidValue;      // even stem map: model.1 output = half of it
     const size_t lds = stem1_lds_bytes(a.TH, a.TW);
     if (lds > 160 * 1024 || (4 * a.TH + 3) * (4 * a.TW + 3) > STEM1_MAXIT * STEM1_NW * 64) return hipErrorInvalidValue;
-    Stem1Args b = a;
-    b.total_tiles = a.tiles_x * a.tiles_y * n;
-    const int per_cu = lds > 0 ? (int)((160 * 1024) / lds) : 1;                       // resident workgroups per CU (LDS-limited)
-    const int grid = std::min(b.total_tiles, std::max(1, per_cu) * num_cus());
-    hipLaunchKernelGGL(stem_model1_kernel<STEM1_NW>, dim3(grid), dim3(STEM1_NW * 64), lds, s, b);
+    hipLaunchKernelGGL(stem_model1_kernel<STEM1_NW>, dim3(a.tiles_x * a.tiles_y, n), dim3(STEM1_NW * 64), lds, s, a);
     return hipGetLastError();
 }
 

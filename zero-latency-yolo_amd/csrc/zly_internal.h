@@ -114,7 +114,6 @@ struct Stem1Args {
     int H1, W1;                               // model.1 output map
     int TH, TW, tiles_x, tiles_y;
     int dump;
-    int total_tiles;                          // tiles_x * tiles_y * frames (set by launch_stem_model1)
 };
 void       stem1_plan(int H1, int W1, int* th, int* tw);
 hipError_t stem1_init();
