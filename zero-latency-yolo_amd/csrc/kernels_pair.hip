@@ -21,6 +21,7 @@
 // (tools/lds_pitch.py).
 #include "zly_internal.h"
 #include "conv_device.h"
+#include <stdlib.h>
 
 namespace zly {
 
@@ -636,7 +637,8 @@ bool c2f_plan(int c, int mode, int nk1, int nk2, int cout2, int n, int H, int W,
     double best = 1e30;
     for (int th = 4; th <= 32; ++th) {
         for (int tw = 8; tw <= 64; ++tw) {
-            if (c2f_lds_bytes(c, mode, nk1, nk2, cout2, th, tw) > (size_t)PAIR_LDS_MAX) continue;
+            static const size_t lds_cap = getenv("ZLY_C2F_LDS_KB") ? (size_t)atoi(getenv("ZLY_C2F_LDS_KB")) * 1024 : (size_t)PAIR_LDS_MAX;    // tuning aid
+            if (c2f_lds_bytes(c, mode, nk1, nk2, cout2, th, tw) > lds_cap) continue;
             if (!(mode & 1) && (th + 4) * (tw + 4) * (c / 8) > nw * 64 * C2F_NLD) continue;
             const int tx = (W + tw - 1) / tw, ty = (H + th - 1) / th;
             const long tiles = (long)n * tx * ty;
