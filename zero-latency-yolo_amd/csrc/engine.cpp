@@ -1550,19 +1550,8 @@ static int detect_host_locked(zly_engine* e, int32_t n, const uint8_t* const* bg
     int rc = ensure_stage(e, total);
     if (rc != ZLY_OK) return rc;
     HIP_TRY(hipStreamSynchronize(e->stream), ZLY_ERR_INFERENCE);        // pinned staging is reused call to call
-    if (n == 1 && total >= (256u << 10)) {
-        // latency path: the copy into pinned memory (~50 us for a 416x416 frame) and the upload are pipelined in four chunks, so the
-        // DMA of chunk k runs under the memcpy of chunk k+1
-        const size_t chunk = (total / 4 + 4095) / 4096 * 4096;
-        for (size_t o = 0; o < total; o += chunk) {
-            const size_t len = std::min(chunk, total - o);
-            memcpy(e->h_stage + o, bgr[0] + o, std::min(len, nbytes[0] > o ? nbytes[0] - o : 0));
-            HIP_TRY(hipMemcpyAsync(e->d_stage + o, e->h_stage + o, len, hipMemcpyHostToDevice, e->stream), ZLY_ERR_INFERENCE);
-        }
-    } else {
-        for (int i = 0; i < n; ++i) memcpy(e->h_stage + offs[(size_t)i], bgr[i], nbytes[i]);
-        HIP_TRY(hipMemcpyAsync(e->d_stage, e->h_stage, total, hipMemcpyHostToDevice, e->stream), ZLY_ERR_INFERENCE);
-    }
+    for (int i = 0; i < n; ++i) memcpy(e->h_stage + offs[(size_t)i], bgr[i], nbytes[i]);
+    HIP_TRY(hipMemcpyAsync(e->d_stage, e->h_stage, total, hipMemcpyHostToDevice, e->stream), ZLY_ERR_INFERENCE);
     rc = set_desc(e, n, w, h, offs.data(), e->stream);
     if (rc != ZLY_OK) return rc;
     rc = run_path(e, n, e->d_stage, nullptr, 0, e->stream, true);
