@@ -42,8 +42,8 @@ $(OUT)/libzly_plugin.so: $(HOST)/hip_inference_engine.cpp $(HOST)/hip_inference_
 $(OUT)/test_hip_engine: tests/cpp/test_hip_engine.cpp $(OUT)/libzly_plugin.so
 	$(CXX) -O2 -std=c++17 -Iinclude -I$(HOST) -o $@ tests/cpp/test_hip_engine.cpp -Wl,--no-as-needed -L$(OUT) -lzly_plugin -lzly -pthread -Wl,-rpath,'$$ORIGIN'
 
-$(OUT)/zly_h2h_bench: tests/cpp/bench_h2h.cpp $(OUT)/libzly_plugin.so
-	$(CXX) -O2 -std=c++17 -Wall -Iinclude -I$(HOST) -o $@ tests/cpp/bench_h2h.cpp -Wl,--no-as-needed -L$(OUT) -lzly_plugin -lzly -pthread -Wl,-rpath,'$$ORIGIN'
+$(OUT)/zly_h2h_bench: $(PKG)/tools/bench_h2h.cpp $(OUT)/libzly_plugin.so
+	$(CXX) -O2 -std=c++17 -Wall -Iinclude -I$(HOST) -o $@ $(PKG)/tools/bench_h2h.cpp -Wl,--no-as-needed -L$(OUT) -lzly_plugin -lzly -pthread -Wl,-rpath,'$$ORIGIN'
 
 $(OUT)/test_frame_server: tests/cpp/test_frame_server.cpp $(HOST)/zly_frame_server.hpp $(HOST)/zly_wire.hpp $(HOST)/zly_game_step.hpp $(OUT)/libzly_plugin.so
 	$(CXX) -O2 -std=c++17 -Wall -Iinclude -I$(HOST) -o $@ tests/cpp/test_frame_server.cpp -Wl,--no-as-needed -L$(OUT) -lzly_plugin -lzly -pthread -Wl,-rpath,'$$ORIGIN'

@@ -42,33 +42,30 @@ PEAK_HBM_GBS = 8000.0         # HBM3E spec peak
 ATTAINABLE_HBM_GBS = 6290.0   # the bandwidth the per-layer attainable time is priced against
 
 
-def per_launch_roofline(ops, kernels, ms, nb):
-    """per launch  attainable_us = max(flops / peak_mfma, bytes / 6.29 TB/s)  next to the achieved time, and their sum.
-    flops / bytes are ALGORITHMIC per op (2 * MAC; input read once + output written once + weights, un-fused) times the frames
-    of the launch; ops that a fused kernel covers (second conv of a bottleneck pair, preprocess inside the stem) are merged
-    into the launch that runs them.  frac = attainable / achieved (1.0 = on its roofline; a fused launch can exceed 1 against
-    the un-fused byte count)."""
-    rows = []
-    carry_gf = carry_mb = 0.0
-    for o, k, m in zip(ops, kernels, ms):
-        gf, mb = o["flops"] * nb / 1e9, o["bytes"] * nb / 1e6
-        if m <= 0:
-            if o["kind"] == 1 and rows:            # second conv of a fused bottleneck pair: ran inside the previous launch
-                rows[-1]["gflop"] += gf; rows[-1]["MB"] += mb
-                rows[-1]["op"] += "+" + o["name"].split(".")[-1]
-            else:                                  # preprocess inside the stem kernel / Detect levels covered by the last tail launch
-                carry_gf += gf; carry_mb += mb
-            continue
-        rows.append({"op": o["name"], "kernel": k, "kind": o["kind"], "us": float(m) * 1e3, "gflop": gf + carry_gf, "MB": mb + carry_mb})
-        carry_gf = carry_mb = 0.0
+def per_launch_roofline(ops, kernels, launches, ms, nb):
+    """SURVEY 8d per launch: attainable_us = max(flops / peak_mfma, bytes / 6.29 TB/s) next to the achieved time.
+    The engine fuses ops into launches depending on the batch size; zly_launch_info_at says which launch covers which ops and what its
+    algorithmic work is.  Two byte counts per launch: `MB_unfused` = the sum of its ops' own algorithmic bytes (every op reads its input
+    and writes its output once) and `MB` = fused-algorithmic = what has to cross the launch boundary (inputs not produced inside the launch +
+    outputs read outside it + weights).  A launch is priced against `MB`; weights count once per launch, not per frame.
+    frac = attainable / achieved <= 1 (1.0 = on its roofline)."""
     out = []
-    for r in rows:
-        t_mfma = r["gflop"] * 1e9 / (PEAK_BF16_TFLOPS * 1e12) * 1e6
-        t_hbm = r["MB"] * 1e6 / (ATTAINABLE_HBM_GBS * 1e9) * 1e6
+    for i, (o, k, li, m) in enumerate(zip(ops, kernels, launches, ms)):
+        if li["covered_by"] != i or m <= 0:
+            continue
+        gf = li["flops_per_frame"] * nb / 1e9
+        mb = ((li["bytes_fused_per_frame"] - li["weight_bytes"]) * nb + li["weight_bytes"]) / 1e6
+        mbu = ((li["bytes_unfused_per_frame"] - li["weight_bytes"]) * nb + li["weight_bytes"]) / 1e6
+        us = float(m) * 1e3
+        t_mfma = gf * 1e9 / (PEAK_BF16_TFLOPS * 1e12) * 1e6
+        t_hbm = mb * 1e6 / (ATTAINABLE_HBM_GBS * 1e9) * 1e6
         att = max(t_mfma, t_hbm)
-        out.append({"op": r["op"], "kernel": r["kernel"], "us": round(r["us"], 2), "gflop": round(r["gflop"], 3), "MB": round(r["MB"], 2),
-                    "attainable_us": round(att, 2), "bound": "mfma" if t_mfma >= t_hbm else "hbm", "frac": round(att / r["us"], 4),
-                    "TFLOPs": round(r["gflop"] / r["us"] * 1e3, 1), "GBps": round(r["MB"] / r["us"] * 1e3, 0), "is_conv": r["kind"] == 1})
+        covered = [ops[j]["name"] for j, lj in enumerate(launches) if lj["covered_by"] == i and j != i]
+        out.append({"op": o["name"], "covers": covered, "kernel": k, "kind": o["kind"], "us": round(us, 2), "gflop": round(gf, 3), "MB": round(mb, 2),
+                    "MB_unfused": round(mbu, 2), "attainable_us": round(att, 2),
+                    "bound": ("mfma" if t_mfma >= t_hbm else "hbm") if att > 0 else "latency",
+                    "frac": round(att / us, 4), "TFLOPs": round(gf / us * 1e3, 1), "mfma_frac": round(gf / us * 1e3 / PEAK_BF16_TFLOPS, 4),
+                    "GBps": round(mb / us * 1e3, 0), "hbm_frac": round(mb / us * 1e3 / PEAK_HBM_GBS, 4), "is_conv": o["kind"] == 1})
     return out
 
 
@@ -92,60 +89,80 @@ def host_cores():
 FORCE_GATHER = os.environ.get("ZLY_BENCH_FORCE_GATHER") == "1"
 
 
-def run_steps(engs, frame_sets, batch, steps, slabs, stream_ptr, world, gather_out, size=416):
-    """enqueue `steps` steps, step k on engine k % len(engs).
+def run_steps(engs, frame_sets, batch, steps, slabs, stream_ptr, world, gather_out, size=416, k0=0):
+    """enqueue `steps` steps (global step numbers k0 .. k0+steps-1), step k on engine k % len(engs).
     One engine: it enqueues on the caller's stream and runs NMS of step k on its own stream beside the first kernels of step k+1
     (ZLY_FLAG_ASYNC_NMS).  Several engines (ZLY_FLAG_SINGLE_CHAIN): each step is one chain of launches on its engine's own stream and
-    the chains of consecutive steps overlap -- what one chain leaves idle at its ~50 kernel boundaries and in its latency-bound small-map
+    the chains of consecutive steps overlap -- what one chain leaves idle at its ~40 kernel boundaries and in its latency-bound small-map
     layers, the others fill.  With world > 1 the slabs of step k are all-gathered once step k+1 has been enqueued: zly_join orders the
-    caller's stream behind step k's NMS, then the collective is queued -- overlapped with the following steps."""
+    caller's stream behind step k's NMS, then the collective is queued -- overlapped with the following steps.
+    Slab ring: len(slabs) should be a multiple of len(engs), so that a slab buffer is always written by the same engine (whose calls are
+    stream-ordered among themselves); a buffer is rewritten only after the gather that read it has COMPLETED (an event behind the
+    gather, waited for on the host -- it finished `ring` steps ago)."""
     import torch.distributed as dist
     n_eng = len(engs)
     ring = len(slabs)
-    works = {}
+    works, done = {}, {}
     gather = world > 1 or FORCE_GATHER
+    on_gpu = slabs[0].is_cuda
 
     def gather_step(j, lag):
         engs[j % n_eng].join(stream_ptr, lag)
         if j - 2 in works:
             works.pop(j - 2).wait()                    # gather buffer j%2 is free again once its previous gather finished
         works[j] = dist.all_gather_into_tensor(gather_out[j % 2], slabs[j % ring], async_op=True)
+        if on_gpu:
+            works[j].wait()                            # orders the caller's stream (joins + gathers only) behind the collective: no host wait
+            done[j] = torch.cuda.Event()
+            done[j].record()
 
-    for k in range(steps):
+    for k in range(k0, k0 + steps):
         d = frame_sets[k % len(frame_sets)]
         if k - ring in works:
             works.pop(k - ring).wait()                 # the slab buffer of step k - ring has been gathered
+        if k - ring in done:
+            done.pop(k - ring).synchronize()           # ... really: the engine's own stream is about to overwrite it
         engs[k % n_eng].detect_device(d.data_ptr(), batch, size, size, d_slabs_ptr=slabs[k % ring].data_ptr(), tag0=k * batch,
                                       stream=stream_ptr if n_eng == 1 else 0)
-        if gather and k > 0:
+        if gather and k > k0:
             gather_step(k - 1, 1 if n_eng == 1 else 0)     # one engine: NMS(k-1), not NMS(k) -- step k+1 must not queue behind NMS(k)
     if gather and steps > 0:
-        gather_step(steps - 1, 0)
+        gather_step(k0 + steps - 1, 0)
     for w in works.values():
         w.wait()
     for e in engs:
         e.join(stream_ptr)                             # every engine's last NMS is ordered into the timed stream
 
 
-def timed(engs, frame_sets, batch, steps, warmup, slabs, stream_ptr, world, gather_out, size=416):
+def timed_blocks(engs, frame_sets, batch, steps, warmup, blocks, slabs, stream_ptr, world, gather_out, size=416):
+    """`warmup` untimed steps, then `blocks` consecutive blocks of EXACTLY `steps` steps, each bracketed by barrier +
+    torch.cuda.synchronize() on both sides and timed with the maximum over ranks.  Returns the list of block times in seconds.
+    Why blocks: the chip ramps its clock for the first ~50 steps after an idle phase (measured: 0.94 -> 0.72 ms/step over the first
+    60 batch-64 steps, again after 2 s of idling; tools/first_steps.py) -- a single 20-step window measured right after 5 warm-up steps
+    lies inside that ramp.  The median block is the steady state the metric is about; all block times are reported."""
     import torch.distributed as dist
-    run_steps(engs, frame_sets, batch, warmup, slabs, stream_ptr, world, gather_out, size)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run_steps(engs, frame_sets, batch, steps, slabs, stream_ptr, world, gather_out, size)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    return dt
+    run_steps(engs, frame_sets, batch, warmup, slabs, stream_ptr, world, gather_out, size, k0=0)
+    k0 = warmup
+    out = []
+    for _ in range(blocks):
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_steps(engs, frame_sets, batch, steps, slabs, stream_ptr, world, gather_out, size, k0=k0)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        out.append(dt)
+        k0 += steps
+    return out
 
 
 def cpu_baseline(frames_np, seconds=12.0):
@@ -190,19 +207,19 @@ def cpu_baseline(frames_np, seconds=12.0):
 
 def host_to_host(threads, seconds=4.0, max_batch=64, engines=1):
     """SURVEY 8d's throughput metric proper: request bytes in HOST memory -> detections in HOST memory, `threads` submitting host
-    threads (config 3: >= 8).  Measured natively by _build/zly_h2h_bench (tests/cpp/bench_h2h.cpp: no interpreter between the
-    threads and the C ABI), once through zly_submit / zly_wait and once through HipInferenceEngine::submitInference ->
-    InferenceCallback (what the reference's NetworkServer drives).  Frames are pageable host memory; the figure includes the
-    one host copy into the pinned ring, the PCIe upload (overlapped with the previous batch's compute) and the slab download."""
+    threads (config 3: >= 8).  Measured natively by _build/zly_h2h_bench (zero-latency-yolo_amd/tools/bench_h2h.cpp: no interpreter
+    between the threads and the C ABI), once through zly_submit / zly_wait, once through HipInferenceEngine::submitInference ->
+    InferenceCallback (what the reference's NetworkServer drives), and once as ONE client sending lone frames through the plugin
+    (the latency a client of the server sees).  Frames are pageable host memory; the figures include the one host copy into the
+    pinned ring, the PCIe upload (overlapped with the previous batch's compute) and the slab download."""
     import subprocess
     exe = os.path.join(ROOT, "zero-latency-yolo_amd", "_build", "zly_h2h_bench")
-    out = {"threads": threads, "engines": engines, "pcie_ceiling_frames_per_sec": round(63e9 / 519168, 0),
-           "note": "pageable host frames -> zly_submit (copy into the pinned ring on the submitting thread) -> H2D on a copy stream beside "
-                   "the previous batch's compute -> path -> slab D2H -> zly_wait; 63 GB/s PCIe Gen5 x16 / 519168 B = 121 k frames/s ceiling"}
-    for mode in ("cabi", "plugin"):
+    out = {"threads": threads, "engines": engines, "pcie_ceiling_frames_per_sec": round(63e9 / 519168, 0)}
+    for mode in ("cabi", "plugin", "lone"):
         try:
-            r = subprocess.run([exe, zly.DEFAULT_WEIGHTS, mode, str(threads), str(seconds), str(max_batch), str(engines)],
-                               capture_output=True, text=True, timeout=120)
+            args = [exe, zly.DEFAULT_WEIGHTS, mode, str(threads if mode != "lone" else 1), str(seconds if mode != "lone" else 2.0), str(max_batch),
+                    str(engines if mode != "lone" else 1)]
+            r = subprocess.run(args, capture_output=True, text=True, timeout=120)
             line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
             out[mode] = json.loads(line[-1]) if (r.returncode == 0 and line) else {"error": (r.stderr or r.stdout)[-400:], "rc": r.returncode}
         except Exception as exc:       # noqa: BLE001  (a failing leg must not take the headline down)
@@ -242,7 +259,9 @@ def run():
     ap.add_argument("--engines", type=int, default=3, help="engine instances per GPU fed alternate steps (ZLY_FLAG_SINGLE_CHAIN when > 1); 1 = one engine with "
                                                           "side streams + deferred NMS")
     ap.add_argument("--sync-nms", action="store_true", help="run NMS in stream order at the end of every step instead of beside the next step's first kernels")
-    ap.add_argument("--dump-ops", default="", help="write the per-op hipEvent profile (name, ms, GFLOP, GB, TFLOP/s, GB/s) to this file")
+    ap.add_argument("--dump-ops", default="", help="write the per-launch hipEvent profile as a text table to this file")
+    ap.add_argument("--blocks", type=int, default=0, help="timed blocks of --steps steps each (default: max(10, ceil(400 / steps))); the median block is reported")
+    ap.add_argument("--per-launch-out", default=os.path.join(ROOT, "gpurun_out", "bench_per_launch.json"), help="where the per-launch roofline tables go (kept out of the JSON line)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -296,36 +315,42 @@ def run():
     sb = eng.slab_bytes
 
     def slab_bufs(n):
-        return [torch.zeros(n * sb, dtype=torch.uint8, device="cuda") for _ in range(n_eng + 3)]   # step k's slabs are gathered while the next steps run / are enqueued
+        return [torch.zeros(n * sb, dtype=torch.uint8, device="cuda") for _ in range(2 * n_eng if n_eng > 1 else 4)]   # a multiple of n_eng: see run_steps
 
     def gather_bufs(n):
         return [torch.zeros(world * n * sb, dtype=torch.uint8, device="cuda") for _ in range(2)] if (world > 1 or force_gather) else None
 
-    log(f"engine ready (rank {rank}/{world}), headline leg: batch {B} x {a.steps} steps")
-    # ---- headline: BASELINE config[1] (batch B per GPU per step) -----------------------------------
+    n_blocks = a.blocks if a.blocks > 0 else max(10, -(-400 // max(1, a.steps)))
+    log(f"engine ready (rank {rank}/{world}), headline leg: batch {B}, {a.warmup} warm-up steps, {n_blocks} blocks x {a.steps} steps")
+    # ---- headline: BASELINE configs[2] (batch B per GPU per step) -----------------------------------
     gb_head = gather_bufs(B)
-    dt = timed(engs, sets_b, B, a.steps, a.warmup, slab_bufs(B), sp, world, gb_head, a.size)
+    slabs_head = slab_bufs(B)
+    bt = timed_blocks(engs, sets_b, B, a.steps, a.warmup, n_blocks, slabs_head, sp, world, gb_head, a.size)
+    dt = float(np.median(bt))
     value = world * B * a.steps / dt
     ms_per_step = dt / a.steps * 1e3
     result = {
         "metric": "frames_per_sec", "value": round(value, 1), "unit": "frames/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 5),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"YOLOv8-{'nano' if a.scale == 'n' else 'small'} {a.size}x{a.size} batch={B} streaming throughput path, bf16{' (fp8 e4m3 weight file)' if a.fp8 else ''}, per MI355X, frames resident in HBM, "
-                               f"preprocess+forward+decode+NMS per step" + (f", steps alternate over {n_eng} engine instances whose chains overlap" if n_eng > 1 else "") +
-                               (", slabs all-gathered over RCCL" if world > 1 else ""),
-                   "engines_per_gpu": n_eng,
-                   "frames_per_step_per_gpu": B, "global_frames_per_step": world * B, "conf": 0.5, "iou": 0.45,
+        "config": {"workload": f"YOLOv8-{'nano' if a.scale == 'n' else 'small'} {a.size}x{a.size} batch={B} throughput path (BASELINE configs[2]), bf16{', fp8 e4m3 weight file' if a.fp8 else ''}",
+                   "detail": f"per MI355X, frames resident in HBM, preprocess+forward+decode+NMS per step" + (f", steps alternate over {n_eng} engine instances whose chains overlap" if n_eng > 1 else "") +
+                             (", slabs all-gathered over RCCL" if world > 1 else ""),
+                   "engines_per_gpu": n_eng, "frames_per_step_per_gpu": B, "global_frames_per_step": world * B, "conf": 0.5, "iou": 0.45,
                    "weights": "seeded synthetic (no real weights offline)", "graph": not a.eager,
-                   "parallelism": f"frame-sharded x{world}" if world > 1 else "single GPU"},
+                   "parallelism": f"frame-sharded x{world}" if world > 1 else "single GPU",
+                   "timing": f"median of {n_blocks} consecutive blocks of {a.steps} steps, each bracketed by barrier+sync (max over ranks)"},
+        "blocks_ms_per_step": [round(t / a.steps * 1e3, 4) for t in bt],
+        "first_block_ms_per_step": round(bt[0] / a.steps * 1e3, 4), "best_block_ms_per_step": round(min(bt) / a.steps * 1e3, 4),
     }
+    lat_b1 = None
     if not a.no_extras:
         # ---- BASELINE configs[1]: batch 1, the latency path, frames resident in HBM ---------------------
         k1 = max(200, a.steps * 2)
-        log(f"headline {value:.0f} frames/s; batch-1 leg")
-        dt1 = timed(engs[:1], sets_1, 1, k1, max(20, a.warmup), slab_bufs(1), sp, world, gather_bufs(1))      # the latency path: ONE in-order chain
-        result["latency_path_b1"] = {"value": round(world * k1 / dt1, 1), "unit": "frames/s", "steps": k1,
-                                     "ms_per_step": round(dt1 / k1 * 1e3, 5), "frames_per_step_per_gpu": 1}
+        log(f"headline {value:.0f} frames/s (blocks ms/step: {result['blocks_ms_per_step']}); batch-1 leg")
+        bt1 = timed_blocks(engs[:1], sets_1, 1, k1, max(20, a.warmup), 5, slab_bufs(1), sp, world, gather_bufs(1))      # the latency path: ONE in-order chain
+        dt1 = float(np.median(bt1))
+        lat_b1 = {"value": round(world * k1 / dt1, 1), "unit": "frames/s", "steps": k1, "ms_per_step_device_resident": round(dt1 / k1 * 1e3, 5)}
         if rank == 0:
             # ---- p50 detect latency, request bytes in host memory -> detections in host memory -----------
             log("latency leg")
@@ -338,14 +363,14 @@ def run():
                 eng.detect(f_host[i % 16])
                 lat.append(time.perf_counter() - t0)
             lat = np.array(lat) * 1e3
-            result["latency_path_b1"].update({"p50_detect_ms_host_to_host": round(float(np.percentile(lat, 50)), 4),
-                                              "p90_detect_ms_host_to_host": round(float(np.percentile(lat, 90)), 4),
-                                              "p99_detect_ms_host_to_host": round(float(np.percentile(lat, 99)), 4), "samples": len(lat),
-                                              "note": "zly_detect: 519 KB H2D over PCIe + path + slab D2H, synchronous"})
+            lat_b1.update({"p50_detect_ms_host_to_host": round(float(np.percentile(lat, 50)), 4),
+                           "p90_detect_ms_host_to_host": round(float(np.percentile(lat, 90)), 4),
+                           "p99_detect_ms_host_to_host": round(float(np.percentile(lat, 99)), 4), "samples": len(lat),
+                           "path": "zly_detect: 519 KB H2D over PCIe + path + slab D2H, synchronous"})
             # ---- roofline of the dominant kernel family (the MFMA conv launches of one forward) ----------
             log("roofline leg (per-op hipEvent profile)")
             ops = eng.ops()
-            roof = {}
+            roof, tables = {}, {}
             # Two per-launch measures, both with hipEvents on the engine's stream (zly_profile_ops):
             #  * one launch per event pair -- includes the few microseconds an event pair adds, as rocprofv3's
             #    per-dispatch durations do (the committed profiles/*_kernel_stats.csv agree with THIS figure);
@@ -356,89 +381,125 @@ def run():
                 ms8 = eng.profile_ops(frames.data_ptr(), nb, 416, 416, reps=10)
                 os.environ["ZLY_PROFILE_INNER"] = "1"
                 ms = eng.profile_ops(frames.data_ptr(), nb, 416, 416, reps=20)
-                launches = per_launch_roofline(ops, eng.op_kernels(nb), ms, nb)
-                conv_l = [r for r in launches if r["is_conv"]]
+                rows = per_launch_roofline(ops, eng.op_kernels(nb), eng.launches(nb), ms, nb)
+                conv_l = [r for r in rows if r["is_conv"]]
                 dom = max(conv_l, key=lambda r: r["us"])
-                conv = [(o, m) for o, m in zip(ops, ms) if o["kind"] == 1 and m > 0]   # m == 0: fused into the previous launch (bottleneck pairs); its flops still count below
+                conv_us = sum(r["us"] for r in conv_l)
                 conv8_ms = float(sum(m for o, m in zip(ops, ms8) if o["kind"] == 1))
-                conv_ms = float(sum(m for _, m in conv))
-                flops = sum(o["flops"] for o in ops if o["kind"] == 1) * nb
-                bytes_ = sum(o["bytes"] for o in ops if o["kind"] == 1) * nb
-                tfl = flops / (conv_ms * 1e-3) / 1e12
-                gbs = bytes_ / (conv_ms * 1e-3) / 1e9
-                top = sorted(conv, key=lambda t: -t[1])[:3]
-                roof[nb] = {"bound": "mfma", "kernel": "conv3x3_lds + conv_igemm + conv1x1_stream + bottleneck_pair + stem_fused (all MFMA conv launches of one forward)",
-                            "launches_per_step": len(conv), "achieved": round(tfl, 3), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                            "frac": round(tfl / PEAK_BF16_TFLOPS, 5), "traffic": None,
-                            "algorithmic_gflop_per_step": round(flops / 1e9, 3), "kernel_ms_per_step": round(conv_ms, 4),
-                            "avg_launch_us": round(conv_ms / len(conv) * 1e3, 3),
-                            "hbm_view": {"algorithmic_GB_per_step": round(bytes_ / 1e9, 4), "achieved_GBps": round(gbs, 1),
-                                         "peak_GBps": PEAK_HBM_GBS, "frac": round(gbs / PEAK_HBM_GBS, 4)},
-                            "all_ops_ms_per_step": round(float(ms.sum()), 4),
-                            "other_ops_ms": {o["name"]: round(float(m), 4) for o, m in zip(ops, ms) if o["kind"] != 1},
-                            "slowest_convs_ms": {o["name"]: round(float(m), 4) for o, m in top},
-                            "back_to_back": {"kernel_ms_per_step": round(conv8_ms, 4), "achieved": round(flops / (conv8_ms * 1e-3) / 1e12, 3),
-                                             "frac": round(flops / (conv8_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 5)},
-                            "method": "zly_profile_ops: 20 eager passes on the engine's stream, one hipEvent pair per launch (back_to_back: 8 launches per pair, / 8)",
-                            # per-layer attainable time next to achieved
-                            "attainable_ms_per_step": round(sum(r["attainable_us"] for r in launches) / 1e3, 4),
-                            "attainable_conv_ms_per_step": round(sum(r["attainable_us"] for r in conv_l) / 1e3, 4),
-                            "achieved_over_attainable": round(float(ms.sum()) / max(1e-9, sum(r["attainable_us"] for r in launches) / 1e3), 2),
-                            "dominant_kernel": {"op": dom["op"], "kernel": dom["kernel"], "us": dom["us"], "bound": dom["bound"],
-                                                "achieved": dom["TFLOPs"] if dom["bound"] == "mfma" else dom["GBps"],
-                                                "unit": "TFLOP/s" if dom["bound"] == "mfma" else "GB/s",
-                                                "peak": PEAK_BF16_TFLOPS if dom["bound"] == "mfma" else PEAK_HBM_GBS,
-                                                "frac_of_peak": round((dom["TFLOPs"] / PEAK_BF16_TFLOPS) if dom["bound"] == "mfma" else (dom["GBps"] / PEAK_HBM_GBS), 4),
-                                                "attainable_us": dom["attainable_us"], "frac_of_attainable": dom["frac"],
-                                                "mfma_frac": round(dom["TFLOPs"] / PEAK_BF16_TFLOPS, 4)},
-                            "per_launch": [{k: v for k, v in r.items() if k != "is_conv"} for r in launches] if nb == B else None}
+                gflop = sum(r["gflop"] for r in conv_l)
+                mb_f = sum(r["MB"] for r in conv_l)
+                mb_u = sum(r["MB_unfused"] for r in conv_l)
+                tfl = gflop / conv_us * 1e3
+                gbs = mb_f / conv_us * 1e3
+                # the family's bound = the bound that most of its kernel time sits under in the per-launch model
+                t_hbm = sum(r["us"] for r in conv_l if r["bound"] == "hbm")
+                bound = "hbm" if t_hbm * 2 >= conv_us else "mfma"
+                att = sum(r["attainable_us"] for r in rows)
+                att_conv = sum(r["attainable_us"] for r in conv_l)
+                roof[nb] = {"bound": bound,
+                            "achieved": round(gbs if bound == "hbm" else tfl, 1), "peak": PEAK_HBM_GBS if bound == "hbm" else PEAK_BF16_TFLOPS,
+                            "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
+                            "frac": round((gbs / PEAK_HBM_GBS) if bound == "hbm" else (tfl / PEAK_BF16_TFLOPS), 5), "traffic": None,
+                            "kernel": "all MFMA conv launches of one forward (stem_model1 / c2f / conv3x3_lds / conv1x1_stream / conv_igemm / bottleneck_pair)",
+                            "bound_rule": f"{t_hbm / conv_us:.0%} of the conv kernel time is in launches whose per-launch model bound is hbm",
+                            "launches_per_step": len(conv_l), "kernel_ms_per_step": round(conv_us / 1e3, 4), "avg_launch_us": round(conv_us / len(conv_l), 2),
+                            "algorithmic_gflop_per_step": round(gflop, 2), "algorithmic_GB_per_step_fused": round(mb_f / 1e3, 4),
+                            "algorithmic_GB_per_step_unfused": round(mb_u / 1e3, 4),
+                            "mfma_achieved_tflops": round(tfl, 1), "mfma_frac": round(tfl / PEAK_BF16_TFLOPS, 5),
+                            "hbm_achieved_GBps": round(gbs, 1), "hbm_frac": round(gbs / PEAK_HBM_GBS, 5),
+                            "back_to_back_kernel_ms_per_step": round(conv8_ms, 4), "back_to_back_mfma_frac": round(gflop / conv8_ms / PEAK_BF16_TFLOPS, 5),
+                            "all_launches_ms_per_step": round(sum(r["us"] for r in rows) / 1e3, 4),
+                            "attainable_ms_per_step": round(att / 1e3, 4), "attainable_conv_ms_per_step": round(att_conv / 1e3, 4),
+                            "achieved_over_attainable": round(sum(r["us"] for r in rows) / max(1e-9, att), 2),
+                            "dominant_op": dom["op"], "dominant_kernel": dom["kernel"], "dominant_us": dom["us"], "dominant_bound": dom["bound"],
+                            "dominant_GBps": dom["GBps"], "dominant_hbm_frac": dom["hbm_frac"], "dominant_TFLOPs": dom["TFLOPs"], "dominant_mfma_frac": dom["mfma_frac"],
+                            "dominant_frac_of_attainable": dom["frac"],
+                            "other_launches_us": {r["op"]: r["us"] for r in rows if not r["is_conv"]},
+                            "method": "zly_profile_ops: 20 eager passes on the engine's stream, one hipEvent pair per launch; bytes = fused-algorithmic (zly_launch_info_at)"}
+                tables[nb] = [{k: v for k, v in r.items() if k != "is_conv"} for r in rows]
                 if a.dump_ops:
                     with open(a.dump_ops, "a") as f:
-                        f.write(f"# batch {nb}: per-op mean ms over 20 eager reps (hipEvents around every launch)\n")
-                        f.write(f"{'op':44s} {'kind':>4s} {'ms':>9s} {'GFLOP':>9s} {'MB':>9s} {'TFLOP/s':>9s} {'GB/s':>9s}\n")
-                        for o, m in zip(ops, ms):
-                            gf, mb = o["flops"] * nb / 1e9, o["bytes"] * nb / 1e6
-                            f.write(f"{o['name']:44s} {o['kind']:4d} {m:9.4f} {gf:9.3f} {mb:9.2f} {gf / max(m, 1e-9):9.2f} {mb / max(m, 1e-9):9.1f}\n")
-                        f.write(f"{'TOTAL':44s} {'':4s} {float(ms.sum()):9.4f}\n\n")
+                        f.write(f"# batch {nb}: per-launch mean us over 20 eager reps (hipEvents around every launch); MB = fused-algorithmic\n")
+                        f.write(f"{'op':40s} {'kernel':46s} {'us':>8s} {'GFLOP':>8s} {'MB':>8s} {'MBunf':>8s} {'att_us':>7s} {'frac':>6s} {'TFLOP/s':>8s} {'GB/s':>7s} bound\n")
+                        for r in rows:
+                            f.write(f"{r['op'][:40]:40s} {r['kernel'][:46]:46s} {r['us']:8.2f} {r['gflop']:8.3f} {r['MB']:8.2f} {r['MB_unfused']:8.2f} {r['attainable_us']:7.2f} "
+                                    f"{r['frac']:6.3f} {r['TFLOPs']:8.1f} {r['GBps']:7.0f} {r['bound']}\n")
+                        f.write(f"{'TOTAL':40s} {'':46s} {sum(r['us'] for r in rows):8.2f}\n\n")
+            # the per-launch tables go to a file (the JSON line stays small enough for the driver to keep all of it)
+            try:
+                os.makedirs(os.path.dirname(a.per_launch_out), exist_ok=True)
+                with open(a.per_launch_out, "w") as f:
+                    json.dump({"batch": B, "per_launch": tables[B], "per_launch_b1": tables[1] if B != 1 else None,
+                               "note": "per launch: us = hipEvent time; MB = fused-algorithmic bytes, MB_unfused = sum of the covered ops' own bytes; attainable_us = max(gflop / 2.5 PF, MB / 6.29 TB/s); frac = attainable / achieved"}, f, indent=1)
+                roof[B]["per_launch_file"] = os.path.relpath(a.per_launch_out, ROOT)
+            except OSError as exc:
+                roof[B]["per_launch_file"] = f"not written: {exc}"
+            bad = [r["op"] for r in tables[B] if r["frac"] > 1.0]
+            roof[B]["launches_with_frac_above_1"] = bad
             # HBM-side traffic of the same kernels from the PMC counters (collected off-line with rocprofv3, two
             # --pmc passes, gfx950 correction applied; see the file for provenance): per batch-64 step
-            tpath = os.path.join(ROOT, "profiles", "r02_traffic_b64.json")
-            if B == 64 and os.path.exists(tpath):
-                tj = json.load(open(tpath))
-                roof[B]["traffic"] = tj["traffic_bytes_per_step"]
-                roof[B]["traffic_note"] = "bytes per step from " + os.path.relpath(tpath, ROOT) + ": " + tj["correction"]
-            roof[B]["whole_step"] = {"note": "algorithmic conv flops of a step / wall time per step (overlapping chains included)",
-                                     "achieved": round(roof[B]["algorithmic_gflop_per_step"] / ms_per_step, 1), "unit": "TFLOP/s",
-                                     "frac": round(roof[B]["algorithmic_gflop_per_step"] / ms_per_step / PEAK_BF16_TFLOPS, 4)}
+            for tp in ("r03_traffic_b64.json", "r02_traffic_b64.json"):
+                tpath = os.path.join(ROOT, "profiles", tp)
+                if B == 64 and os.path.exists(tpath):
+                    tj = json.load(open(tpath))
+                    roof[B]["traffic"] = tj["traffic_bytes_per_step"]
+                    roof[B]["traffic_over_fused_algorithmic"] = round(tj["traffic_bytes_per_step"] / (roof[B]["algorithmic_GB_per_step_fused"] * 1e9), 3)
+                    roof[B]["traffic_note"] = "bytes per step from profiles/" + tp + " (rocprofv3 --pmc, FETCH_SIZE doubled per the gfx950 note, WRITE_SIZE as read)"
+                    break
+            roof[B]["whole_step_tflops"] = round(roof[B]["algorithmic_gflop_per_step"] / ms_per_step, 1)
+            roof[B]["whole_step_mfma_frac"] = round(roof[B]["algorithmic_gflop_per_step"] / ms_per_step / PEAK_BF16_TFLOPS, 4)
             result["roofline"] = roof[B]
             if B != 1:
-                result["roofline_b1"] = roof[1]
+                r1 = roof[1]
+                result["roofline_b1"] = {k: r1[k] for k in ("bound", "launches_per_step", "kernel_ms_per_step", "avg_launch_us", "mfma_frac", "hbm_frac",
+                                                            "back_to_back_kernel_ms_per_step", "all_launches_ms_per_step", "attainable_ms_per_step")}
             hdrs = [h for h, _ in eng.read_slabs(min(B, 64))]
-            result["candidates_per_frame_last_profiled_batch"] = {"median": float(np.median([int(h["n_candidates"]) for h in hdrs])),
-                                                                  "max": int(max(int(h["n_candidates"]) for h in hdrs)),
-                                                                  "kept_max": int(max(int(h["n_kept"]) for h in hdrs))}
-    if rank == 0 and world == 1 and not a.no_extras and os.environ.get("ZLY_BENCH_NO_H2H") != "1":
-        log("host-to-host throughput leg (native driver, 2 x ~5 s)")
-        h2h = host_to_host(max(8, min(12, host_cores() - 3)), engines=2)      # 2 engines + the shared upload stream = one hardware queue per stream (DESIGN.md section 4)
-        result["throughput_host_to_host"] = h2h
-        if "frames_per_sec" in h2h.get("cabi", {}):
-            result["throughput_host_to_host"]["frac_of_device_resident"] = round(h2h["cabi"]["frames_per_sec"] / value, 3)
+            result["candidates_per_frame"] = {"median": float(np.median([int(h["n_candidates"]) for h in hdrs])),
+                                              "max": int(max(int(h["n_candidates"]) for h in hdrs)), "kept_max": int(max(int(h["n_kept"]) for h in hdrs))}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(frames_np[:8])
         result["speedup_vs_cpu_baseline"] = round(value / result["cpu_baseline"]["value"], 1)
     st = eng.stats()
     result["engine_stats"] = {"inference_count": st["inference_count"], "inference_errors": st["inference_errors"]}
     if world > 1 or force_gather:
-        # the gathered slabs of the last headline step, back in global frame order, must be well-formed
-        g = shard.global_order(gb_head[(a.steps - 1) % 2], world * B, world, sb)
+        # the gathered slabs of the last headline step, back in global frame order, must be well-formed, and this rank's slice of them must
+        # be, byte for byte, what ONE engine writes for the same frames in a plain synchronous call
+        last = a.warmup + n_blocks * a.steps - 1
+        g = shard.global_order(gb_head[last % 2], world * B, world, sb)
         hd = g[:, :16].contiguous().view(torch.int32).cpu().numpy()
         assert (hd[:, 0] >= 0).all() and (hd[:, 1] >= hd[:, 0]).all(), "malformed gathered slabs"
-        result["gather"] = {"ranks": world, "bytes_per_rank_per_step": B * sb, "frames_checked": int(hd.shape[0])}
+        ref_slab = torch.zeros(B * sb, dtype=torch.uint8, device="cuda")
+        eng.detect_device(sets_b[last % len(sets_b)].data_ptr(), B, a.size, a.size, d_slabs_ptr=ref_slab.data_ptr(), tag0=last * B, stream=sp if n_eng == 1 else 0)
+        eng.join(sp)
+        torch.cuda.synchronize()
+        mine = gb_head[last % 2].view(world, B * sb)[rank]
+        assert torch.equal(mine, ref_slab), "gathered slabs of the last step differ from a single-engine run on the same frames"
+        result["gather"] = {"ranks": world, "bytes_per_rank_per_step": B * sb, "frames_checked": int(hd.shape[0]), "equals_single_engine_run": True}
         dist.barrier()
+    if rank == 0 and world == 1 and not a.no_extras and os.environ.get("ZLY_BENCH_NO_H2H") != "1":
+        for e_ in engs:                # the native driver creates its own engines: free this process's first
+            e_.close()
+        engs = []
+        log("host-to-host legs (native driver: C ABI, plugin, lone client)")
+        h2h = host_to_host(max(8, min(12, host_cores() - 3)), engines=2)      # 2 engines + the shared upload stream = one hardware queue per stream (DESIGN.md section 4)
+        keep = ("frames_per_sec", "pcie_h2d_GBps", "p50_ms", "p99_ms", "avg_batch", "errors", "error")
+        result["throughput_host_to_host"] = {"threads": h2h["threads"], "engines": h2h["engines"], "pcie_ceiling_frames_per_sec": h2h["pcie_ceiling_frames_per_sec"],
+                                             "cabi": {k: v for k, v in h2h.get("cabi", {}).items() if k in keep},
+                                             "plugin": {k: v for k, v in h2h.get("plugin", {}).items() if k in keep}}
+        if "frames_per_sec" in h2h.get("cabi", {}):
+            result["throughput_host_to_host"]["frac_of_device_resident"] = round(h2h["cabi"]["frames_per_sec"] / value, 3)
+        if lat_b1 is not None and "p50_ms" in h2h.get("lone", {}):
+            lo = h2h["lone"]
+            lat_b1["plugin_lone_client"] = {"p50_ms": lo["p50_ms"], "p90_ms": lo["p90_ms"], "p99_ms": lo["p99_ms"], "frames_per_sec": lo["frames_per_sec"],
+                                            "path": "one client, HipInferenceEngine::submitInference -> InferenceCallback, lone frames (batch-1 graph replayed by the pipelined path)"}
+        elif lat_b1 is not None:
+            lat_b1["plugin_lone_client"] = h2h.get("lone")
     for e_ in engs:
         e_.close()
     if world > 1 or force_gather:
         dist.destroy_process_group()
+    if lat_b1 is not None:
+        result["latency_path_b1"] = lat_b1          # BASELINE's "p50 detect latency": LAST, so that it is in the tail of the line whatever is cut
     return json.dumps(result) if rank == 0 else None
 
 

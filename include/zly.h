@@ -30,8 +30,9 @@
  *   return codes               zero_latency::ErrorCode             src/common/result.h:14-48
  *
  * Threading: one engine handle may be used from several host threads; calls on one handle are
- * serialised internally (the reference serialises Session::Run the same way, onnx_engine.cpp:577), and the enqueue
- * sections of ALL engines of a process are serialised among themselves (~0.1 ms each; stream capture is process-global in HIP).
+ * serialised internally (the reference serialises Session::Run the same way, onnx_engine.cpp:577).  Enqueue sections of DIFFERENT
+ * engines of a process run concurrently; only stream capture (at zly_create, and on the first synchronous call of a new batch size) and
+ * device allocation / release (zly_create, zly_destroy, the first zly_submit) are alone in the process.
  * Ownership: the caller owns every host buffer for the duration of the call; the engine owns all
  * device and pinned memory.  There is NO CPU fallback: without a usable HIP device zly_create
  * fails with ZLY_ERR_SYSTEM.
@@ -69,7 +70,8 @@ extern "C" {
                                    (stream order) or zly_sync / zly_read_slabs (host), whichever comes first. */
 #define ZLY_FLAG_SINGLE_CHAIN 16 /* no side streams: the whole step is one chain of launches on one stream.  For SEVERAL engines per GPU fed alternate
                                    batches (their chains overlap each other: the idle time at every kernel boundary of one is filled by the other);
-                                   needs one hardware queue per stream, i.e. GPU_MAX_HW_QUEUES=8 in the environment before HIP starts */
+                                   each such engine owns exactly one stream, so that up to three of them fit the four hardware queues ROCm gives a process by default
+                                   (leave GPU_MAX_HW_QUEUES alone: 8 measured 2x SLOWER on the host-to-host path) */
 #define ZLY_FLAG_NO_FUSION   2   /* run every conv as its own kernel (no fused bottleneck pairs): every zly_debug_tap is then available */
 
 typedef struct zly_engine zly_engine;
@@ -103,11 +105,12 @@ typedef struct zly_config {
     int32_t model_w, model_h;   /* detection.model_width/height, multiples of 32 (config.h:110-149) */
     float conf_thr;             /* confidence_threshold, default 0.5 (configs/server.json:7) */
     float iou_thr;              /* nms_threshold, default 0.45 (configs/server.json:8) */
-    int32_t max_batch;          /* frames per zly_detect_batch / zly_detect_device call */
+    int32_t max_batch;          /* frames per zly_detect_batch / zly_detect_device call (1..65535) */
     int32_t max_dets;           /* slab capacity per frame (cap) */
     int32_t device;             /* HIP device ordinal */
     int32_t dtype;              /* ZLY_DTYPE_* */
-    int32_t warmup_runs;        /* warmupModel analogue, onnx_engine.cpp:919-954 (reference: 3) */
+    int32_t warmup_runs;        /* warmupModel analogue, onnx_engine.cpp:919-954 (reference: 3): that many single-frame passes, then -- when > 0 and
+                                   max_batch > 1 -- the throughput path at max_batch (graphs for batch 1 and max_batch are captured and replayed here) */
     int32_t use_graph;          /* 1: replay the forward as a hipGraph per batch size */
     int32_t flags;              /* ZLY_FLAG_* */
 } zly_config;
@@ -181,8 +184,9 @@ int32_t zly_detect_device(zly_engine* e, int32_t n, const void* d_frames, int32_
 size_t  zly_slab_bytes(const zly_engine* e);
 int32_t zly_read_slabs(zly_engine* e, int32_t n, void* host_slabs);   /* syncs the engine stream */
 int32_t zly_sync(zly_engine* e);
-/* ZLY_FLAG_ASYNC_NMS: make `stream` (NULL = the engine's own) wait, on the device, for the NMS of every zly_detect_device
- * call made so far except the last `lag` ones (lag = 1: consume call k-1's slabs right after enqueuing call k). */
+/* Make `stream` (NULL = the engine's own) wait, on the device, for the NMS of every zly_detect_device call made so far except the
+ * last `lag` ones.  lag must be 0 or 1 (lag = 1: consume call k-1's slabs right after enqueuing call k); the engine keeps the
+ * completion events of its last two calls only, any other lag fails with ZLY_ERR_INVALID_ARGUMENT. */
 int32_t zly_join(zly_engine* e, void* stream, int32_t lag);
 
 /* --- stage-level entry points (parity tests) ------------------------------------------------- */
@@ -210,6 +214,21 @@ int32_t zly_weights_fp8(const zly_engine* e);
 int32_t zly_num_anchors(const zly_engine* e);
 int32_t zly_num_ops(const zly_engine* e);
 int32_t zly_op_info_at(const zly_engine* e, int32_t i, zly_op_info* out);
+/* Launch groups: the engine fuses ops into one kernel depending on the batch size (preprocess + model.0 + model.1; whole C2f blocks;
+ * bottleneck pairs; the Detect tail of all levels; merged Detect launches on the latency path).  For op i at batch size n:
+ * covered_by = the op whose launch does op i's work (== i when op i launches itself; then the other fields describe that launch):
+ * n_ops it covers, their summed algorithmic flops and un-fused bytes, and bytes_fused = what has to cross the launch boundary
+ * (inputs not produced inside the group + outputs read outside the group + weights) -- the byte count a fused launch's HBM
+ * roofline is priced against (bench.py). */
+typedef struct zly_launch_info {
+    int32_t covered_by;
+    int32_t n_ops;
+    double flops_per_frame;
+    double bytes_unfused_per_frame;
+    double bytes_fused_per_frame;
+    double weight_bytes;              /* part of both byte counts; per launch, not per frame */
+} zly_launch_info;
+int32_t zly_launch_info_at(zly_engine* e, int32_t i, int32_t n, zly_launch_info* out);
 /* name and tile shape of the kernel op i launches at batch size n (the engine picks kernels per launch size) */
 int32_t zly_op_kernel_name(zly_engine* e, int32_t i, int32_t n, char* out, size_t cap);
 /* Runs the device path `reps` times on n resident frames with a hipEvent pair around every

@@ -36,12 +36,42 @@ def _boxes(d):
     return np.stack([d["x"], d["y"], d["w"], d["h"]], 1).astype(np.float64) if len(d) else np.zeros((0, 4))
 
 
-def compare_detection_sets(oracle, ref_head, got, img_w, img_h, conf=0.5, iou_thr=0.45, band=2e-2, min_iou=0.9):
+def measured_bands(ref_head, other_head, conf=0.5, iou_thr=0.45, margin=2.0, floor=2e-3, cap=2e-2):
+    """The threshold-flip bands of ONE frame from the deviation actually present between two head tensors [4+nc][N] of that
+    frame (the fp32 oracle's and the engine's own, or -- where the engine does not materialise its head -- the bf16-rounding
+    oracle's, i.e. the noise floor of bf16 on this frame).  SURVEY 8c's band (2e-2) is the TOLERANCE; the deviation really
+    present is ~5x smaller, and a set comparison that skips everything within the tolerance of a threshold compares a minority
+    of the detections on a head whose scores are a smooth (Gaussian-tailed) distribution through 0.5.  A flip needs a score
+    (an IoU) to be on different sides of its threshold in the two tensors, which cannot happen further from the threshold than
+    the largest deviation near it.  Returns (band_score, band_iou) = margin x that largest deviation over the (class, anchor)
+    entries scoring >= conf - 0.1 resp. over the same-class candidate pairs with IoU >= 0.2, clamped to [floor, cap]: never
+    looser than SURVEY's band, never tighter than `floor`."""
+    a = np.asarray(ref_head, dtype=np.float64)
+    b = np.asarray(other_head, dtype=np.float64)
+    near = a[4:] >= conf - 0.1
+    ds = float(np.abs(a[4:] - b[4:])[near].max()) if near.any() else 0.0
+    anc = np.nonzero(near.any(0))[0]
+    di = 0.0
+    if len(anc) > 1:
+        cls = a[4:, anc].argmax(0)
+        ia, ib = _iou_matrix(a[:4, anc].T, a[:4, anc].T), _iou_matrix(b[:4, anc].T, b[:4, anc].T)
+        pair = (cls[:, None] == cls[None]) & (ia >= 0.2)
+        np.fill_diagonal(pair, False)
+        if pair.any():
+            di = float(np.abs(ia - ib)[pair].max())
+    clamp = lambda v: float(min(cap, max(floor, margin * v)))
+    return clamp(ds), clamp(di)
+
+
+def compare_detection_sets(oracle, ref_head, got, img_w, img_h, conf=0.5, iou_thr=0.45, band=2e-2, min_iou=0.9, band_iou=None):
     """oracle: tests/oracle_lib.Oracle; ref_head: fp32 oracle head tensor [4+nc][N] of the frame; got: the engine's
-    detections (structured zly_det array).  Returns (n_compared, n_skipped, errors): detections compared exactly,
-    oracle detections skipped inside ambiguous components, list of error strings (empty = parity holds)."""
+    detections (structured zly_det array); band: half-width of the score flip band (also the confidence tolerance of matched
+    detections); band_iou: half-width of the IoU flip band (default: band) -- SURVEY 8c's 2e-2, or this frame's measured_bands().
+    Returns (n_compared, n_skipped, errors): detections compared exactly, oracle detections skipped inside ambiguous
+    components, list of error strings (empty = parity holds)."""
     want = oracle.postprocess(ref_head, img_w, img_h, conf, iou_thr)
     errors = []
+    band_iou = band if band_iou is None else band_iou
     # nodes: (anchor, class) pairs the engine may legitimately report -- the anchor's best class, plus every class within
     # `band` of it, when they score >= conf - band (postProcess keeps the arg-max class only, onnx_engine.cpp:787-799)
     ref_head = np.asarray(ref_head, dtype=np.float32)
@@ -68,12 +98,12 @@ def compare_detection_sets(oracle, ref_head, got, img_w, img_h, conf=0.5, iou_th
     if n:
         iou = _iou_matrix(nb, nb)
         same = nodes["class_id"][:, None] == nodes["class_id"][None]
-        ii, jj = np.nonzero(np.triu(same & (iou >= iou_thr - band), 1))
+        ii, jj = np.nonzero(np.triu(same & (iou >= iou_thr - band_iou), 1))
         for i, j in zip(ii, jj):
             ri, rj = find(i), find(j)
             if ri != rj:
                 comp[ri] = rj
-            if abs(iou[i, j] - iou_thr) <= band:
+            if abs(iou[i, j] - iou_thr) <= band_iou:
                 amb_edges.append(i)
             elif abs(float(nodes["confidence"][i]) - float(nodes["confidence"][j])) <= band:
                 # the greedy order of i and j may swap: harmless unless they differ in which same-class boxes they suppress

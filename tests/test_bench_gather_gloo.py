@@ -56,7 +56,7 @@ def _worker(rank, world, port, n_eng, q):
     registry = {}
     engs = [FakeEngine(registry, cap, rank) for _ in range(n_eng)]
     sb = engs[0].slab_bytes
-    slabs = [torch.zeros(batch * sb, dtype=torch.uint8) for _ in range(n_eng + 3)]
+    slabs = [torch.zeros(batch * sb, dtype=torch.uint8) for _ in range(2 * n_eng if n_eng > 1 else 4)]      # as bench.py: a multiple of n_eng
     for t in slabs:
         registry[t.data_ptr()] = t
     gather_out = [torch.zeros(world * batch * sb, dtype=torch.uint8) for _ in range(2)]

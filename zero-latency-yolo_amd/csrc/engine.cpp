@@ -80,7 +80,11 @@ struct Op {
     int c2f_leader = -1;               // index of the leader op (resolved after the ops are ordered)
     int c2f_vis = 0;                   // this op's output with the fused kernel: 0 = in HBM, 1 = only with ZLY_FLAG_DUMP_LOGITS, 2 = stays in LDS
     HeadArgs head{};                   // OP_HEAD: fused Detect tail
+    int head_box[3] = {-1, -1, -1}, head_cls[3] = {-1, -1, -1};     // OP_HEAD: buffers the tail reads per level (launch-group bookkeeping)
     double flops = 0, bytes = 0;
+    double wbytes = 0;                 // weight + bias bytes of this op (part of `bytes`)
+    double cin_frac = 1.0;             // real / stored input channels (the 3-of-8 channel image, the 80-of-96 channel class branch)
+    std::map<int, ConvLaunch> launch_cache;    // batch size -> kernel shape of the per-conv path (conv_pick_config reads the environment: once per shape, not per launch)
 };
 
 struct Ingest;        // pipelined host-to-host path (zly_submit / zly_wait), below
@@ -147,7 +151,8 @@ struct zly_engine {
     hipStream_t stream = nullptr;
     hipStream_t side[2] = {nullptr, nullptr};     // P3 / P4 Detect branches (forked from and joined to the main stream)
     hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join[2] = {nullptr, nullptr};
-    std::map<int, hipGraphExec_t> graphs;   // batch size -> captured forward+decode
+    std::map<int, hipGraphExec_t> graphs;   // (batch size, fused front, candidate-buffer parity) -> captured forward+decode
+    std::map<int, int> graph_failures;      // failed captures per key (a second failure leaves the shape on eager launches)
     std::map<long, std::pair<bool, C2fPlan>> c2f_plans;     // (c, mode, n, H, W) -> fused C2f tile plan
     std::map<long, std::pair<bool, PairPlan>> pair_plans;   // (c, n, H, W) -> fused bottleneck tile plan (or "run unfused")
     int last_n = 0;
@@ -168,6 +173,9 @@ struct zly_engine {
     int cu_part_n = 1;                // ZLY_CU_PART: number of CU partitions (1 = whole chip)
     uint32_t cu_mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     std::atomic<Ingest*> ingest{nullptr};   // created by the first zly_submit (under mu), read lock-free afterwards
+
+    // tuning / test switches of the environment, read ONCE at zly_create (they used to be read per launch)
+    struct Switches { bool no_c2f = false, no_det_merge = false, no_tail_split = false, no_lanes = false; } sw;
 
     std::mutex mu;                    // serialises every call that touches engine / device state
     mutable std::mutex stats_mu;      // guards `stats` only, never held across a device call: zly_get_stats cannot wait on a batch
@@ -256,8 +264,10 @@ struct PlanBuilder {
         }
         op.flops = 2.0 * macs;
         const double osz = out_f32 ? 4.0 : (double)e->esz;
-        op.bytes = ((double)ib.H * ib.W * in.C + (in2.buf >= 0 ? (double)Ho * Wo * in2.C : 0.0)) * e->esz * ((double)r0->cin / cin_total) + (double)Ho * Wo * op.cout * osz +
-                   (double)op.cout * r0->cin * op.ks * op.ks * e->esz + (res.buf >= 0 ? (double)Ho * Wo * op.cout * e->esz : 0.0);
+        op.cin_frac = (double)r0->cin / cin_total;
+        op.wbytes = (double)op.cout * r0->cin * op.ks * op.ks * e->esz + (double)op.cout * 4.0;
+        op.bytes = ((double)ib.H * ib.W * in.C + (in2.buf >= 0 ? (double)Ho * Wo * in2.C : 0.0)) * e->esz * op.cin_frac + (double)Ho * Wo * op.cout * osz +
+                   op.wbytes + (res.buf >= 0 ? (double)Ho * Wo * op.cout * e->esz : 0.0);
         e->ops.push_back(op);
         for (size_t i = 0; i < names.size(); ++i) e->tap_index[names[i]] = std::make_pair((int)e->ops.size() - 1, (int)i);
         return true;
@@ -490,7 +500,10 @@ static int build_plan(zly_engine* e, std::string* err)
         block0 += (hl.hw + 63) / 64;
         const double macs = (double)hl.hw * (c2 * 64.0 + (double)c3 * m.nc);
         hd.flops += 2.0 * macs;
-        hd.bytes += (double)hl.hw * ((c2 + c3) * (double)e->esz + (4 + m.nc) * 4.0) + (c2 * 64.0 + (double)c3 * m.nc) * e->esz;
+        // algorithmic bytes: both branch activations in, the weights, and -- only when the engine materialises it -- the fp32 head tensor out
+        hd.bytes += (double)hl.hw * ((c2 + c3) * (double)e->esz + ((e->cfg.flags & ZLY_FLAG_NO_HEAD_TENSOR) ? 0.0 : (4 + m.nc) * 4.0)) + (c2 * 64.0 + (double)c3 * m.nc) * e->esz;
+        hd.wbytes += (c2 * 64.0 + (double)c3 * m.nc) * e->esz;
+        hd.head_box[l] = hb2; hd.head_cls[l] = hc2;
         e->tap_final[std::string("model.22.cv2.") + L + ".2"] = std::make_pair(hout, 0);
         e->tap_final[std::string("model.22.cv3.") + L + ".2"] = std::make_pair(hout, 64);
         e->lvl_h[l] = fh[l]; e->lvl_w[l] = fw[l];
@@ -505,7 +518,7 @@ static int build_plan(zly_engine* e, std::string* err)
         t.level = l;
         t.name = std::string("detect.tail.P") + std::to_string(3 + l) + (l == 2 ? " (all levels below batch 16)" : "");
         const double share = (double)hd.head.lv[l].hw / (double)e->N;
-        t.flops = hd.flops * share; t.bytes = hd.bytes * share;
+        t.flops = hd.flops * share; t.bytes = hd.bytes * share; t.wbytes = hd.wbytes * share;
         e->ops.push_back(t);
     }
     if (!ok) { *err = pb.err; return ZLY_ERR_MODEL_LOAD; }
@@ -613,8 +626,7 @@ static int build_plan(zly_engine* e, std::string* err)
 static bool lanes_active(const zly_engine* e, int n)
 {
     if (e->cfg.flags & ZLY_FLAG_SINGLE_CHAIN) return false;
-    static const bool no_lanes = getenv("ZLY_NO_LANES") != nullptr || getenv("ZLY_CU_PART") != nullptr;     // tuning aid; a CU partition runs one chain
-    return n >= 16 && !no_lanes;
+    return n >= 16 && !e->sw.no_lanes;                               // ZLY_NO_LANES / ZLY_CU_PART: tuning aid; a CU partition runs one chain
 }
 
 // Fused bottleneck pair for this op at batch n?  Only degenerate launches (a handful of tiles) stay on the per-conv
@@ -641,7 +653,7 @@ static const PairPlan* pair_active(zly_engine* e, const Op& op, int n)
 static const C2fPlan* c2f_active(zly_engine* e, const Op& L, int n)
 {
     if (!L.c2f_mode || e->dtype != ZLY_DTYPE_BF16 || (e->cfg.flags & ZLY_FLAG_NO_FUSION)) return nullptr;
-    if (getenv("ZLY_NO_C2F") != nullptr) return nullptr;                    // tuning / tests
+    if (e->sw.no_c2f) return nullptr;                                       // ZLY_NO_C2F: tuning / tests
     const Buffer& b = e->bufs[(size_t)L.c2f_cat];
     const long key = ((((long)L.c2f_c * 4 + L.c2f_mode) * 4096 + n) * 4096 + b.H) * 4096 + b.W;
     auto it = e->c2f_plans.find(key);
@@ -684,10 +696,27 @@ static ConvArgs make_conv_args(zly_engine* e, const Op& op, int n)
     return a;
 }
 
+// kernel shape of the per-conv path for op at batch n: picked once per (op, batch size) -- conv_pick_config reads ~10 environment
+// switches, which the eager path (partial batches of the pipelined host path) used to do for every conv of every call
+static const ConvLaunch& conv_launch_of(zly_engine* e, const Op& op, int n)
+{
+    Op& mop = const_cast<Op&>(op);
+    auto it = mop.launch_cache.find(n);
+    if (it == mop.launch_cache.end()) {
+        const Buffer& ob = e->bufs[(size_t)op.out.buf];
+        const int cin = op.in.C + (op.in2.buf >= 0 ? op.in2.C : 0);
+        ConvLaunch c;
+        conv_pick_config(e->dtype, op.ks, op.stride, cin, op.cout_pad, n, ob.H, ob.W, &c,
+                         op.in2.buf < 0 && op.res.buf < 0 && op.act && !op.out_f32 && op.cout % 32 == 0);
+        it = mop.launch_cache.emplace(n, c).first;
+    }
+    return it->second;
+}
+
 // Detect convs merged into two launches on the latency path (conv_igemm_multi_kernel): batch <= 4, no side streams in use
 static bool detect_merge_active(zly_engine* e, int n)
 {
-    if (e->dtype != ZLY_DTYPE_BF16 || e->det_stem[0] < 0 || n > 4 || lanes_active(e, n) || getenv("ZLY_NO_DET_MERGE") != nullptr) return false;
+    if (e->dtype != ZLY_DTYPE_BF16 || e->det_stem[0] < 0 || n > 4 || lanes_active(e, n) || e->sw.no_det_merge) return false;
     return true;
 }
 // role of op index i in the merged Detect launches: 0 none, 1 covered (no launch), 2 launches the three stems, 3 launches the six branch convs
@@ -709,8 +738,64 @@ static bool op_is_noop(zly_engine* e, const Op& op, int n)
     if (op.kind == OP_CONV && c2f_covered(e, op, n)) return true;
     if (op.kind == OP_CONV && detect_merge_active(e, n) && detect_merge_role(e, (int)(&op - e->ops.data())) == 1) return true;
     if (op.kind == OP_CONV && op.pair == 2) return pair_active(e, op, n) != nullptr;
-    if (op.kind == OP_HEAD && op.level != 2) return !lanes_active(e, n) || getenv("ZLY_NO_TAIL_SPLIT") != nullptr;
+    if (op.kind == OP_HEAD && op.level != 2) return !lanes_active(e, n) || e->sw.no_tail_split;
     return false;
+}
+
+// Launch groups (bookkeeping for zly_launch_info_at): index of the op whose launch does op i's work at batch n on the detect paths --
+// i itself when it launches, the fused kernel's leader otherwise.
+static int op_covered_by(zly_engine* e, int i, int n)
+{
+    const Op& op = e->ops[(size_t)i];
+    if (op.kind == OP_PREPROCESS) return e->stem_fused ? 1 : i;
+    if (op.kind == OP_CONV) {
+        if (i == 2 && e->stem1) return 1;
+        if (c2f_covered(e, op, n)) return op.c2f_leader;
+        if (detect_merge_active(e, n) && detect_merge_role(e, i) == 1) {
+            for (int l = 0; l < 3; ++l) if (i == e->det_stem[l]) return e->det_stem[2];
+            return e->det_a[2];
+        }
+        if (op.pair == 2 && pair_active(e, op, n)) return i - 1;
+        return i;
+    }
+    if (op.kind == OP_HEAD && op_is_noop(e, op, n)) {
+        for (size_t k = 0; k < e->ops.size(); ++k) if (e->ops[k].kind == OP_HEAD && e->ops[k].level == 2) return (int)k;
+    }
+    return i;
+}
+
+// channel ranges an op reads / writes, as (buffer, first channel, channels, pixels per frame, scale) records
+struct IoView { int buf, co, C; double px, scale; };
+static void op_reads(const zly_engine* e, const Op& op, std::vector<IoView>* out)
+{
+    if (op.kind == OP_CONV) {
+        const Buffer& ib = e->bufs[(size_t)op.in.buf];
+        out->push_back({op.in.buf, op.in.co, op.in.C, (double)ib.H * ib.W, op.cin_frac});
+        if (op.in2.buf >= 0) { const Buffer& b2 = e->bufs[(size_t)op.in2.buf]; out->push_back({op.in2.buf, op.in2.co, op.in2.C, (double)b2.H * b2.W, op.cin_frac}); }
+        if (op.res.buf >= 0) { const Buffer& rb = e->bufs[(size_t)op.res.buf]; out->push_back({op.res.buf, op.res.co, op.res.C > 0 ? op.res.C : op.cout, (double)rb.H * rb.W, 1.0}); }
+    } else if (op.kind == OP_SPPF) {
+        const Buffer& b = e->bufs[(size_t)op.in.buf];
+        out->push_back({op.in.buf, op.in.co, op.c, (double)b.H * b.W, 1.0});
+    } else if (op.kind == OP_HEAD) {                      // a tail op stands for its own level; one launch for all levels = a group of the three
+        const int l = op.level;
+        const Buffer& bb = e->bufs[(size_t)op.head_box[l]];
+        const Buffer& cb = e->bufs[(size_t)op.head_cls[l]];
+        out->push_back({op.head_box[l], 0, bb.C, (double)bb.H * bb.W, 1.0});
+        out->push_back({op.head_cls[l], 0, cb.C, (double)cb.H * cb.W, 1.0});
+    }
+}
+static void op_writes(const zly_engine* e, const Op& op, std::vector<IoView>* out)
+{
+    if (op.kind == OP_CONV) {
+        const Buffer& ob = e->bufs[(size_t)op.out.buf];
+        out->push_back({op.out.buf, op.out.co, op.cout, (double)ob.H * ob.W, 1.0});
+    } else if (op.kind == OP_SPPF) {
+        const Buffer& b = e->bufs[(size_t)op.in.buf];
+        out->push_back({op.in.buf, op.in.co + op.c, 3 * op.c, (double)b.H * b.W, 1.0});
+    } else if (op.kind == OP_PREPROCESS) {
+        const Buffer& b = e->bufs[(size_t)e->in_buf];
+        out->push_back({e->in_buf, 0, 8, (double)b.H * b.W, 3.0 / 8.0});
+    }
 }
 
 static hipError_t run_op(zly_engine* e, const Op& op, int n, const uint8_t* d_src, void* d_slabs_out, uint32_t tag0, hipStream_t s)
@@ -720,7 +805,6 @@ static hipError_t run_op(zly_engine* e, const Op& op, int n, const uint8_t* d_sr
         return launch_preprocess(e->dtype, d_src, e->d_desc, n, e->bufs[(size_t)e->in_buf].ptr, nullptr, e->cfg.model_w, e->cfg.model_h, s);
     case OP_CONV: {
         const Buffer& ib = e->bufs[(size_t)op.in.buf];
-        const Buffer& ob = e->bufs[(size_t)op.out.buf];
         if (c2f_covered(e, op, n)) return hipSuccess;               // computed by the fused C2f kernel launched at its leader
         if (detect_merge_active(e, n)) {
             const int role = detect_merge_role(e, (int)(&op - e->ops.data()));
@@ -773,10 +857,7 @@ static hipError_t run_op(zly_engine* e, const Op& op, int n, const uint8_t* d_sr
             }
         }
         ConvArgs a = make_conv_args(e, op, n);
-        ConvLaunch cfg;
-        conv_pick_config(e->dtype, op.ks, op.stride, a.Cin, op.cout_pad, n, ob.H, ob.W, &cfg,
-                         a.in2 == nullptr && a.res == nullptr && a.act && !a.out_f32 && a.Cout % 32 == 0);
-        return launch_conv(e->dtype, a, cfg, s);
+        return launch_conv(e->dtype, a, conv_launch_of(e, op, n), s);
     }
     case OP_SPPF: {
         const Buffer& b = e->bufs[(size_t)op.in.buf];
@@ -784,8 +865,7 @@ static hipError_t run_op(zly_engine* e, const Op& op, int n, const uint8_t* d_sr
     }
     case OP_HEAD: {
         HeadArgs h = op.head;
-        static const bool no_split = getenv("ZLY_NO_TAIL_SPLIT") != nullptr;   // tuning aid
-        if (lanes_active(e, n) && !no_split) h.only_level = op.level;       // per-level launches (+0.3 % at batch 64)
+        if (lanes_active(e, n) && !e->sw.no_tail_split) h.only_level = op.level;       // per-level launches (+0.3 % at batch 64)
         else if (op.level != 2) return hipSuccess;          // the last tail op covers all levels
         else h.only_level = -1;
         h.head = (e->cfg.flags & ZLY_FLAG_NO_HEAD_TENSOR) ? nullptr : e->d_head; h.desc = e->d_desc; h.conf_thr = e->cfg.conf_thr; h.cand = e->cur_cand; h.cand_count = e->cur_count;
@@ -842,17 +922,44 @@ static hipError_t run_ops(zly_engine* e, size_t first, size_t last, int n, const
 // stream, so waiting for a call's event covers every earlier call.
 static int join_nms(zly_engine* e, hipStream_t s, int lag = 0)
 {
-    if (e->last_async < 0 || lag >= 2) return ZLY_OK;    // nothing outstanding / already ordered: a deferred call waits for the NMS two calls back
+    if (e->last_async < 0) return ZLY_OK;                // nothing outstanding
     const int p = lag == 0 ? e->last_async : e->last_async ^ 1;
     if (e->nms_recorded[p]) HIP_TRY(hipStreamWaitEvent(s, e->ev_nms[p], 0), ZLY_ERR_INFERENCE);
     return ZLY_OK;
 }
 
-// One engine of the process enqueues at a time (~0.1 ms of host work per batch): taken around every enqueue section of every entry point.
-// Reason: stream capture.  With several engines per process (bench --engines, ZLY_ENGINES_PER_GPU) a HIP call from another engine's
-// dispatcher thread while a capture was open -- a launch, an async copy, an event wait -- failed both sides with "operation failed due
-// to a previous error during capture" (thread-local and relaxed capture modes alike).
-static std::mutex g_enqueue_mu;
+// The process-wide enqueue gate.  Enqueue sections of different engines (launches, async copies, event records: ~0.03-0.1 ms of host
+// work per batch) hold it SHARED and run concurrently -- with ZLY_NUM_DEVICES x ZLY_ENGINES_PER_GPU dispatcher threads a single mutex
+// here serialised sixteen threads at the same order of time a GPU needs per batch.  What must be alone in the process holds it
+// EXCLUSIVE: stream capture (a HIP call from another engine's thread while a capture was open -- a launch, an async copy, an event
+// wait -- failed both sides with "operation failed due to a previous error during capture", thread-local and relaxed modes alike) and
+// device allocation / release (zly_create, zly_destroy, the staging ring: hot reload builds engines beside running ones).  Captures
+// happen at zly_create (batch 1 and max_batch) and otherwise only on the first call of a new batch size on the synchronous entry points.
+// Writers are preferred: a waiting capture is not starved by a steady stream of enqueues.
+class EnqueueGate {
+    std::mutex m_;
+    std::condition_variable cv_;
+    int readers_ = 0, writers_waiting_ = 0;
+    bool writer_ = false;
+public:
+    void lock_shared() { std::unique_lock<std::mutex> lk(m_); cv_.wait(lk, [&] { return !writer_ && writers_waiting_ == 0; }); ++readers_; }
+    void unlock_shared() { std::lock_guard<std::mutex> lk(m_); if (--readers_ == 0) cv_.notify_all(); }
+    void lock() { std::unique_lock<std::mutex> lk(m_); ++writers_waiting_; cv_.wait(lk, [&] { return !writer_ && readers_ == 0; }); --writers_waiting_; writer_ = true; }
+    void unlock() { std::lock_guard<std::mutex> lk(m_); writer_ = false; cv_.notify_all(); }
+};
+static EnqueueGate g_gate;
+struct SharedGate {
+    bool held = true;
+    SharedGate() { g_gate.lock_shared(); }
+    ~SharedGate() { if (held) g_gate.unlock_shared(); }
+    void release() { if (held) { g_gate.unlock_shared(); held = false; } }
+    SharedGate(const SharedGate&) = delete; SharedGate& operator=(const SharedGate&) = delete;
+};
+struct ExclusiveGate {
+    ExclusiveGate() { g_gate.lock(); }
+    ~ExclusiveGate() { g_gate.unlock(); }
+    ExclusiveGate(const ExclusiveGate&) = delete; ExclusiveGate& operator=(const ExclusiveGate&) = delete;
+};
 
 // phase timing of the last sampled call, if its events have completed: added to the stats, never waited for
 static void harvest_timing(zly_engine* e)
@@ -913,36 +1020,37 @@ static int run_path(zly_engine* e, int n, const uint8_t* d_src, void* d_slabs_ou
         HIP_TRY(run_op(e, e->ops[0], n, d_src, nullptr, 0, s), ZLY_ERR_INFERENCE);
     }
     if (sample) HIP_TRY(hipEventRecord(e->ev_t[1], s), ZLY_ERR_INFERENCE);
-    // the pipelined host path (several dispatcher threads per process) replays graphs for FULL batches only -- the steady state under
-    // load -- and launches partial batches eagerly: no capture storm over the 63 partial sizes, and no capture while other engines run
-    if (e->cfg.use_graph && !(e->ingest_active && n != e->cfg.max_batch)) {
-        const int key = (n * 2 + (fused ? 1 : 0)) * 2 + par;     // the captured Detect tail holds the candidate buffer's address
-        auto it = e->graphs.find(key);
-        if (it == e->graphs.end()) {
-            // capture on the engine's own stream, then replay on whichever stream the caller uses.  With several engines per process every
-            // enqueue section holds the process-wide g_enqueue_mu (run_path's callers), so no other thread launches anything while a
-            // capture is open: a launch from another engine's dispatcher thread during a thread-local capture failed BOTH with "operation
-            // failed due to a previous error during capture".  A capture that still fails leaves this batch size on eager launches
-            hipGraph_t g = nullptr;
-            hipGraphExec_t ge = nullptr;
-            HIP_TRY(hipStreamSynchronize(s), ZLY_ERR_INFERENCE);
-            {
-                hipError_t r = hipStreamBeginCapture(e->stream, hipStreamCaptureModeRelaxed);
-                if (r == hipSuccess) {
-                    r = run_ops(e, first, nops - 1, n, nullptr, nullptr, 0, e->stream);
-                    hipError_t r2 = hipStreamEndCapture(e->stream, &g);
-                    if (r == hipSuccess) r = r2;
-                }
-                if (r == hipSuccess) r = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
-                if (g) hipGraphDestroy(g);
-                if (r != hipSuccess) { (void)hipGetLastError(); ge = nullptr; }
+    // Graph replay.  Graphs are captured at zly_create for batch 1 and max_batch (warm_batch) and, on the synchronous entry points, on the
+    // first call of any other batch size.  The pipelined host path (dispatcher threads, several per process) never captures: it replays
+    // what exists -- a lone frame and a full batch, its two steady states -- and launches other partial batches eagerly with cached
+    // kernel shapes: no capture storm over the 62 partial sizes, no capture while other engines run.
+    const int key = (n * 2 + (fused ? 1 : 0)) * 2 + par;     // the captured Detect tail holds the candidate buffer's address
+    auto git = e->graphs.find(key);
+    if (e->cfg.use_graph && git == e->graphs.end() && !e->ingest_active) {
+        // Capture on the engine's own stream, then replay on whichever stream the caller uses.  The caller holds the enqueue gate shared;
+        // a capture needs it exclusively (see EnqueueGate).  e->mu is held throughout, so nothing else touches this engine meanwhile.
+        hipGraph_t g = nullptr;
+        hipGraphExec_t ge = nullptr;
+        HIP_TRY(hipStreamSynchronize(s), ZLY_ERR_INFERENCE);
+        g_gate.unlock_shared();
+        {
+            ExclusiveGate x;
+            hipError_t r = hipStreamBeginCapture(e->stream, hipStreamCaptureModeRelaxed);
+            if (r == hipSuccess) {
+                r = run_ops(e, first, nops - 1, n, nullptr, nullptr, 0, e->stream);
+                hipError_t r2 = hipStreamEndCapture(e->stream, &g);
+                if (r == hipSuccess) r = r2;
             }
-            it = e->graphs.emplace(key, ge).first;
+            if (r == hipSuccess) r = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+            if (g) hipGraphDestroy(g);
+            if (r != hipSuccess) { (void)hipGetLastError(); ge = nullptr; }
         }
-        if (!it->second) {
-            HIP_TRY(run_ops(e, first, nops - 1, n, nullptr, nullptr, 0, s), ZLY_ERR_INFERENCE);      // capture failed once for this shape: eager
-        } else
-        HIP_TRY(hipGraphLaunch(it->second, s), ZLY_ERR_INFERENCE);
+        g_gate.lock_shared();
+        // a failed capture is retried once (on the next call of this shape) before the shape is left on eager launches for good
+        if (ge || ++e->graph_failures[key] >= 2) git = e->graphs.emplace(key, ge).first;
+    }
+    if (e->cfg.use_graph && git != e->graphs.end() && git->second) {
+        HIP_TRY(hipGraphLaunch(git->second, s), ZLY_ERR_INFERENCE);
     } else {
         HIP_TRY(run_ops(e, first, nops - 1, n, nullptr, nullptr, 0, s), ZLY_ERR_INFERENCE);
     }
@@ -1025,21 +1133,28 @@ static uint64_t now_ms()
 
 static void ingest_destroy(zly_engine* e);
 
-static void destroy_engine(zly_engine* e)
+// Returns the first HIP error met while draining / releasing (the engine is gone either way).
+static hipError_t destroy_engine(zly_engine* e)
 {
-    if (!e) return;
-    hipSetDevice(e->dev);
-    ingest_destroy(e);
-    if (e->stream) hipStreamSynchronize(e->stream);
-    for (int i = 0; i < 2; ++i) if (e->side[i]) hipStreamSynchronize(e->side[i]);
-    if (e->nms_stream) hipStreamSynchronize(e->nms_stream);
-    for (auto& kv : e->graphs) if (kv.second) hipGraphExecDestroy(kv.second);
-    for (Buffer& b : e->bufs) if (b.ptr) hipFree(b.ptr);
+    if (!e) return hipSuccess;
+    hipError_t first = hipSuccess;
+    auto note = [&](hipError_t r) { if (r != hipSuccess && first == hipSuccess) first = r; };
+    note(hipSetDevice(e->dev));
+    ingest_destroy(e);                                   // joins the dispatcher / completion threads (they take the gate themselves)
+    // drain this engine's streams with no gate held (up to a batch of device time: other engines keep enqueuing) ...
+    if (e->stream) note(hipStreamSynchronize(e->stream));
+    for (int i = 0; i < 2; ++i) if (e->side[i]) note(hipStreamSynchronize(e->side[i]));
+    if (e->nms_stream) note(hipStreamSynchronize(e->nms_stream));
+    // ... and release alone in the process: a hipFree / hipGraphExecDestroy from this thread while another engine (a hot reload builds the
+    // new engines beside the running ones) has a capture open fails both sides
+    ExclusiveGate x;
+    for (auto& kv : e->graphs) if (kv.second) note(hipGraphExecDestroy(kv.second));
+    for (Buffer& b : e->bufs) if (b.ptr) note(hipFree(b.ptr));
     void* dptrs[] = {e->d_weights, e->d_head, e->d_cand, e->d_cand_alt, e->d_count_alt, e->d_scratch, e->d_count, e->d_slabs, e->d_desc, e->d_stage, e->d_scratch_f32};
-    for (void* p : dptrs) if (p) hipFree(p);
-    if (e->h_desc) hipHostFree(e->h_desc);
-    if (e->h_stage) hipHostFree(e->h_stage);
-    if (e->h_slabs) hipHostFree(e->h_slabs);
+    for (void* p : dptrs) if (p) note(hipFree(p));
+    if (e->h_desc) note(hipHostFree(e->h_desc));
+    if (e->h_stage) note(hipHostFree(e->h_stage));
+    if (e->h_slabs) note(hipHostFree(e->h_slabs));
     for (int i = 0; i < 2; ++i) {
         if (e->ev_fork[i]) hipEventDestroy(e->ev_fork[i]);
         if (e->ev_join[i]) hipEventDestroy(e->ev_join[i]);
@@ -1053,6 +1168,7 @@ static void destroy_engine(zly_engine* e)
     if (e->nms_stream) hipStreamDestroy(e->nms_stream);
     if (e->stream) hipStreamDestroy(e->stream);
     delete e;
+    return first;
 }
 
 
@@ -1136,7 +1252,7 @@ static void ingest_close_open(Ingest* g)
 static void ingest_enqueue(zly_engine* e, Ingest* g, IngestSlot& sl)
 {
     std::lock_guard<std::mutex> lk(e->mu);
-    std::lock_guard<std::mutex> gl(g_enqueue_mu);
+    SharedGate gl;
     const int n = sl.n_reserved;
     hipStream_t out_stream = e->stream;
     auto body = [&]() -> int {
@@ -1228,7 +1344,7 @@ static void ingest_free(zly_engine* e, Ingest* g);
 static int ingest_start(zly_engine* e)
 {
     std::lock_guard<std::mutex> lk(e->mu);
-    std::lock_guard<std::mutex> gl(g_enqueue_mu);      // allocations: never while another engine of the process has a capture open
+    ExclusiveGate gl;                                  // allocations: alone in the process (another engine may otherwise have a capture open)
     if (e->ingest.load()) return ZLY_OK;
     HIP_TRY(hipSetDevice(e->dev), ZLY_ERR_SYSTEM);
     Ingest* g = new Ingest();
@@ -1276,15 +1392,18 @@ static void ingest_destroy(zly_engine* e)
     if (g->dispatcher.joinable()) g->dispatcher.join();
     if (g->completer.joinable()) g->completer.join();
     e->ingest.store(nullptr);
-    ingest_free(e, g);
-}
-
-static void ingest_free(zly_engine* e, Ingest* g)
-{
     if (g->copy_stream) hipStreamSynchronize(g->copy_stream);
     if (e->stream) hipStreamSynchronize(e->stream);
     if (e->nms_stream) hipStreamSynchronize(e->nms_stream);
     if (g->d2h_stream) hipStreamSynchronize(g->d2h_stream);
+    ExclusiveGate x;                                   // releases: alone in the process
+    ingest_free(e, g);
+}
+
+// caller holds the exclusive gate and has drained the streams
+static void ingest_free(zly_engine* e, Ingest* g)
+{
+    (void)e;
     for (IngestSlot& sl : g->slots) {
         if (sl.h_stage) hipHostFree(sl.h_stage);
         if (sl.d_stage) hipFree(sl.d_stage);
@@ -1351,7 +1470,7 @@ static IngestSlot* ingest_slot_of(Ingest* g, uint64_t ticket, int* idx)
     const uint64_t batch = ticket >> 16;
     *idx = (int)(ticket & 0xffffu);
     IngestSlot& sl = g->slots[(size_t)(batch % g->slots.size())];
-    if (sl.state == SLOT_FREE || sl.batch != batch || *idx >= sl.n_reserved || sl.consumed[(size_t)*idx]) return nullptr;
+    if (sl.state == SLOT_FREE || sl.batch != batch || *idx >= sl.n_reserved || sl.consumed[(size_t)*idx]) return nullptr;   // consumed: 1 = done, 2 = claimed by a waiter
     return &sl;
 }
 
@@ -1374,8 +1493,11 @@ static int ingest_wait(zly_engine* e, uint64_t ticket, zly_det* out, int32_t cap
     int idx = 0;
     IngestSlot* sl = ingest_slot_of(g, ticket, &idx);
     if (!sl) return fail(ZLY_ERR_INVALID_ARGUMENT, "unknown or already consumed ticket");
+    // the ticket is CLAIMED before the wait: a second zly_wait on it (concurrent, or entered before this one finishes) fails instead of
+    // consuming it twice -- two consumptions freed the ring slot while other tickets of the batch were still unread
+    sl->consumed[(size_t)idx] = 2;
     g->cv_done.wait(lk, [&] { return g->stop || sl->state == SLOT_DONE; });
-    if (sl->state != SLOT_DONE) return fail(ZLY_ERR_NOT_INITIALIZED, "Engine not running");
+    if (sl->state != SLOT_DONE) { sl->consumed[(size_t)idx] = 0; return fail(ZLY_ERR_NOT_INITIALIZED, "Engine not running"); }
     const int rc = sl->rc;
     std::string err = sl->err;
     const uint64_t ts = sl->ts_ms;
@@ -1422,6 +1544,38 @@ void zly_default_config(zly_config* c)
     c->dtype = ZLY_DTYPE_BF16; c->warmup_runs = 3; c->use_graph = 1;
 }
 
+// One untimed pass of the device-resident path at batch n on constant-128 frames, through run_path exactly as zly_detect_device and the
+// pipelined host path run it (deferred NMS: both candidate-buffer parities): captures the batch-n graph(s) and replays each once, so that
+// neither the capture (stream sync + capture + instantiate) nor a graph's first launch falls into a production call -- at start-up or
+// after a hot reload.  warmupModel analogue for the throughput path (onnx_engine.cpp:919-954 warms its single-frame path only).
+static int warm_batch(zly_engine* e, int n)
+{
+    std::lock_guard<std::mutex> lk(e->mu);
+    const size_t fb = (size_t)e->cfg.model_w * e->cfg.model_h * 3;
+    const size_t total = fb * (size_t)n;
+    if (total > e->stage_bytes) {
+        ExclusiveGate x;
+        int rc = ensure_stage(e, total);
+        if (rc != ZLY_OK) return rc;
+    }
+    SharedGate gl;
+    HIP_TRY(hipMemsetAsync(e->d_stage, 128, total, e->stream), ZLY_ERR_INFERENCE);
+    std::vector<int32_t> ws((size_t)n, e->cfg.model_w), hs((size_t)n, e->cfg.model_h);
+    std::vector<size_t> offs((size_t)n);
+    for (int i = 0; i < n; ++i) offs[(size_t)i] = (size_t)i * fb;
+    int rc = set_desc(e, n, ws.data(), hs.data(), offs.data(), e->stream);
+    if (rc != ZLY_OK) return rc;
+    const bool defer = (e->cfg.flags & ZLY_FLAG_ASYNC_NMS) != 0;
+    for (int k = 0; k < (defer ? 4 : 2); ++k) {
+        rc = run_path(e, n, e->d_stage, nullptr, 0, e->stream, true, defer);
+        if (rc != ZLY_OK) return rc;
+    }
+    gl.release();
+    HIP_TRY(hipStreamSynchronize(e->stream), ZLY_ERR_INFERENCE);
+    if (e->nms_stream) HIP_TRY(hipStreamSynchronize(e->nms_stream), ZLY_ERR_INFERENCE);
+    return ZLY_OK;
+}
+
 int32_t zly_create(const zly_config* cfg, zly_engine** out)
 {
     if (!cfg || !out) return fail(ZLY_ERR_INVALID_ARGUMENT, "null argument");
@@ -1429,16 +1583,12 @@ int32_t zly_create(const zly_config* cfg, zly_engine** out)
     if (cfg->model_w <= 0 || cfg->model_h <= 0 || cfg->model_w % 32 || cfg->model_h % 32)
         return fail(ZLY_ERR_INVALID_ARGUMENT, "model_w/model_h must be positive multiples of 32");
     if (cfg->max_batch < 1 || cfg->max_dets < 1) return fail(ZLY_ERR_INVALID_ARGUMENT, "max_batch/max_dets must be >= 1");
+    if (cfg->max_batch > 65535) return fail(ZLY_ERR_INVALID_ARGUMENT, "max_batch must be <= 65535 (a ticket of the pipelined path carries the frame's index in 16 bits)");
     if (cfg->dtype != ZLY_DTYPE_BF16 && cfg->dtype != ZLY_DTYPE_FP32) return fail(ZLY_ERR_INVALID_ARGUMENT, "dtype must be ZLY_DTYPE_FP32 or ZLY_DTYPE_BF16");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(ZLY_ERR_SYSTEM, "no HIP device available: this engine has no CPU fallback");
     if (cfg->device < 0 || cfg->device >= ndev) return fail(ZLY_ERR_INVALID_ARGUMENT, "device ordinal out of range");
-    HIP_TRY(hipSetDevice(cfg->device), ZLY_ERR_SYSTEM);
-    HIP_TRY(conv_init(), ZLY_ERR_SYSTEM);
-    HIP_TRY(pair_init(), ZLY_ERR_SYSTEM);
-    HIP_TRY(stem1_init(), ZLY_ERR_SYSTEM);
-    HIP_TRY(c2f_init(), ZLY_ERR_SYSTEM);
 
     zly_engine* e = new zly_engine();
     e->cfg = *cfg;
@@ -1447,76 +1597,100 @@ int32_t zly_create(const zly_config* cfg, zly_engine** out)
     e->dev = cfg->device;
     e->dtype = cfg->dtype;
     e->esz = cfg->dtype == ZLY_DTYPE_BF16 ? 2 : 4;
+    e->sw.no_c2f = getenv("ZLY_NO_C2F") != nullptr;
+    e->sw.no_det_merge = getenv("ZLY_NO_DET_MERGE") != nullptr;
+    e->sw.no_tail_split = getenv("ZLY_NO_TAIL_SPLIT") != nullptr;
+    e->sw.no_lanes = getenv("ZLY_NO_LANES") != nullptr || getenv("ZLY_CU_PART") != nullptr;
     std::string err;
-    int rc = load_zlyw(e->weights_path.c_str(), &e->model, &err);
-    if (rc != ZLY_OK) { destroy_engine(e); return fail(rc, err); }
+    int rc = load_zlyw(e->weights_path.c_str(), &e->model, &err);        // host only: file parse
+    if (rc != ZLY_OK) { delete e; return fail(rc, err); }
     e->nc = e->model.nc;
-    // ZLY_CU_PART="i/n": this engine's streams only use the i-th of n equal slices of the chip's compute units (spatial
-    // partitioning: several engines run side by side, the launch-latency-bound small-map layers of one beside the
-    // bandwidth-bound layers of another).  Experiment switch: see DESIGN.md section 5.
-    if (const char* cp = getenv("ZLY_CU_PART")) {
-        int pi = 0, pn = 1;
-        if (sscanf(cp, "%d/%d", &pi, &pn) == 2 && pn >= 1 && pn <= 8 && pi >= 0 && pi < pn) {
-            e->cu_part_n = pn;
-            const int per = 256 / pn;
-            for (int b = pi * per; b < (pi + 1) * per; ++b) e->cu_mask[b / 32] |= 1u << (b % 32);
-            set_num_cus(per);
+
+    // Everything that allocates on / uploads to the device runs alone in the process (ExclusiveGate): a hot reload builds new engines beside
+    // running ones, and a hipMalloc / hipMemcpy here while one of them had a stream capture open failed both sides.
+    auto device_setup = [&]() -> int {
+        HIP_TRY(hipSetDevice(cfg->device), ZLY_ERR_SYSTEM);
+        HIP_TRY(conv_init(), ZLY_ERR_SYSTEM);
+        HIP_TRY(pair_init(), ZLY_ERR_SYSTEM);
+        HIP_TRY(stem1_init(), ZLY_ERR_SYSTEM);
+        HIP_TRY(c2f_init(), ZLY_ERR_SYSTEM);
+        // ZLY_CU_PART="i/n": this engine's streams only use the i-th of n equal slices of the chip's compute units (spatial
+        // partitioning: several engines run side by side, the launch-latency-bound small-map layers of one beside the
+        // bandwidth-bound layers of another).  Experiment switch: see DESIGN.md section 5.
+        if (const char* cp = getenv("ZLY_CU_PART")) {
+            int pi = 0, pn = 1;
+            if (sscanf(cp, "%d/%d", &pi, &pn) == 2 && pn >= 1 && pn <= 8 && pi >= 0 && pi < pn) {
+                e->cu_part_n = pn;
+                const int per = 256 / pn;
+                for (int b = pi * per; b < (pi + 1) * per; ++b) e->cu_mask[b / 32] |= 1u << (b % 32);
+                set_num_cus(per);
+            }
         }
-    }
-    auto make_stream = [&](hipStream_t* st) {
-        if (e->cu_part_n > 1) return hipExtStreamCreateWithCUMask(st, 8, e->cu_mask) == hipSuccess;
-        return hipStreamCreateWithFlags(st, hipStreamNonBlocking) == hipSuccess;
+        auto make_stream = [&](hipStream_t* st) {
+            if (e->cu_part_n > 1) return hipExtStreamCreateWithCUMask(st, 8, e->cu_mask) == hipSuccess;
+            return hipStreamCreateWithFlags(st, hipStreamNonBlocking) == hipSuccess;
+        };
+        bool sok = make_stream(&e->stream);
+        // side streams only when the Detect-branch lanes can be used: every stream beyond the hardware-queue limit shares a hardware queue
+        // with another one, and two streams on one queue serialise -- several engines per GPU want few streams each
+        const bool want_lanes = !(cfg->flags & ZLY_FLAG_SINGLE_CHAIN) && !e->sw.no_lanes;
+        for (int i = 0; i < 2 && sok && want_lanes; ++i) {
+            sok = make_stream(&e->side[i]) &&
+                  hipEventCreateWithFlags(&e->ev_fork[i], hipEventDisableTiming) == hipSuccess &&
+                  hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming) == hipSuccess;
+        }
+        if (!sok) return fail(ZLY_ERR_SYSTEM, "hipStreamCreate failed");
+        int prc = build_plan(e, &err);
+        if (prc != ZLY_OK) return fail(prc, err);
+
+        const size_t B = (size_t)cfg->max_batch, N = (size_t)e->N;
+        bool ok = true;
+        ok = ok && hipMalloc((void**)&e->d_head, ((cfg->flags & ZLY_FLAG_NO_HEAD_TENSOR) ? 1 : B) * (4 + (size_t)e->nc) * N * sizeof(float)) == hipSuccess;
+        ok = ok && hipMalloc((void**)&e->d_cand, B * N * sizeof(Cand)) == hipSuccess;
+        ok = ok && hipMalloc((void**)&e->d_scratch, B * N * sizeof(Cand)) == hipSuccess;
+        ok = ok && hipMalloc((void**)&e->d_count, B * sizeof(int)) == hipSuccess;
+        ok = ok && hipMalloc((void**)&e->d_slabs, B * slab_bytes_of(e)) == hipSuccess;
+        ok = ok && hipMalloc((void**)&e->d_desc, B * sizeof(FrameDesc)) == hipSuccess;
+        ok = ok && hipHostMalloc((void**)&e->h_desc, zly_engine::DESC_RING * B * sizeof(FrameDesc), hipHostMallocDefault) == hipSuccess;
+        for (int i = 0; i < zly_engine::DESC_RING && ok; ++i) ok = hipEventCreateWithFlags(&e->ev_desc[i], hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; i < 4 && ok; ++i) ok = hipEventCreate(&e->ev_t[i]) == hipSuccess;
+        for (int i = 0; i < 2 && ok; ++i) ok = hipEventCreateWithFlags(&e->ev_call[i], hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipHostMalloc((void**)&e->h_slabs, B * slab_bytes_of(e), hipHostMallocDefault) == hipSuccess;
+        if (!ok) return fail(ZLY_ERR_SYSTEM, "device allocation failed");
+        ok = hipMemset(e->d_slabs, 0, B * slab_bytes_of(e)) == hipSuccess && hipMemset(e->d_count, 0, B * sizeof(int)) == hipSuccess;
+        e->cur_cand = e->d_cand; e->cur_count = e->d_count;
+        if (ok && (cfg->flags & ZLY_FLAG_ASYNC_NMS)) {
+            ok = hipMalloc((void**)&e->d_cand_alt, B * N * sizeof(Cand)) == hipSuccess && hipMalloc((void**)&e->d_count_alt, B * sizeof(int)) == hipSuccess &&
+                 make_stream(&e->nms_stream) &&
+                 hipEventCreateWithFlags(&e->ev_head, hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&e->ev_nms[0], hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&e->ev_nms[1], hipEventDisableTiming) == hipSuccess &&
+                 hipMemset(e->d_count_alt, 0, B * sizeof(int)) == hipSuccess;
+            if (!ok) return fail(ZLY_ERR_SYSTEM, "device allocation failed (deferred NMS)");
+        }
+        if (!ok) return fail(ZLY_ERR_SYSTEM, "device initialisation failed");
+        // staging for one frame (zly_detect) -- or, with a warm-up, for max_batch model-sized frames (warm_batch; zly_detect_batch then never allocates)
+        const size_t fb = (size_t)cfg->model_w * cfg->model_h * 3;
+        return ensure_stage(e, cfg->warmup_runs > 0 ? fb * B : fb);
     };
-    bool sok = make_stream(&e->stream);
-    // side streams only when the Detect-branch lanes can be used: every stream beyond the hardware-queue limit (GPU_MAX_HW_QUEUES) shares
-    // a hardware queue with another one, and two streams on one queue serialise -- several engines per GPU want few streams each
-    const bool want_lanes = !(cfg->flags & ZLY_FLAG_SINGLE_CHAIN) && getenv("ZLY_NO_LANES") == nullptr && getenv("ZLY_CU_PART") == nullptr;
-    for (int i = 0; i < 2 && sok && want_lanes; ++i) {
-        sok = make_stream(&e->side[i]) &&
-              hipEventCreateWithFlags(&e->ev_fork[i], hipEventDisableTiming) == hipSuccess &&
-              hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming) == hipSuccess;
+    {
+        ExclusiveGate x;
+        rc = device_setup();
     }
-    if (!sok) { destroy_engine(e); return fail(ZLY_ERR_SYSTEM, "hipStreamCreate failed"); }
-    rc = build_plan(e, &err);
-    if (rc != ZLY_OK) { destroy_engine(e); return fail(rc, err); }
+    if (rc != ZLY_OK) { std::string m = g_last_error; destroy_engine(e); return fail(rc, m); }
 
-    const size_t B = (size_t)cfg->max_batch, N = (size_t)e->N;
-    bool ok = true;
-    ok = ok && hipMalloc((void**)&e->d_head, B * (4 + (size_t)e->nc) * N * sizeof(float)) == hipSuccess;
-    ok = ok && hipMalloc((void**)&e->d_cand, B * N * sizeof(Cand)) == hipSuccess;
-    ok = ok && hipMalloc((void**)&e->d_scratch, B * N * sizeof(Cand)) == hipSuccess;
-    ok = ok && hipMalloc((void**)&e->d_count, B * sizeof(int)) == hipSuccess;
-    ok = ok && hipMalloc((void**)&e->d_slabs, B * slab_bytes_of(e)) == hipSuccess;
-    ok = ok && hipMalloc((void**)&e->d_desc, B * sizeof(FrameDesc)) == hipSuccess;
-    ok = ok && hipHostMalloc((void**)&e->h_desc, zly_engine::DESC_RING * B * sizeof(FrameDesc), hipHostMallocDefault) == hipSuccess;
-    for (int i = 0; i < zly_engine::DESC_RING && ok; ++i) ok = hipEventCreateWithFlags(&e->ev_desc[i], hipEventDisableTiming) == hipSuccess;
-    for (int i = 0; i < 4 && ok; ++i) ok = hipEventCreate(&e->ev_t[i]) == hipSuccess;
-    for (int i = 0; i < 2 && ok; ++i) ok = hipEventCreateWithFlags(&e->ev_call[i], hipEventDisableTiming) == hipSuccess;
-    ok = ok && hipHostMalloc((void**)&e->h_slabs, B * slab_bytes_of(e), hipHostMallocDefault) == hipSuccess;
-    if (!ok) { destroy_engine(e); return fail(ZLY_ERR_SYSTEM, "device allocation failed"); }
-    hipMemset(e->d_slabs, 0, B * slab_bytes_of(e));
-    hipMemset(e->d_count, 0, B * sizeof(int));
-    e->cur_cand = e->d_cand; e->cur_count = e->d_count;
-    if (cfg->flags & ZLY_FLAG_ASYNC_NMS) {
-        bool aok = hipMalloc((void**)&e->d_cand_alt, B * N * sizeof(Cand)) == hipSuccess && hipMalloc((void**)&e->d_count_alt, B * sizeof(int)) == hipSuccess &&
-                   make_stream(&e->nms_stream) &&
-                   hipEventCreateWithFlags(&e->ev_head, hipEventDisableTiming) == hipSuccess &&
-                   hipEventCreateWithFlags(&e->ev_nms[0], hipEventDisableTiming) == hipSuccess &&
-                   hipEventCreateWithFlags(&e->ev_nms[1], hipEventDisableTiming) == hipSuccess;
-        if (!aok) { destroy_engine(e); return fail(ZLY_ERR_SYSTEM, "device allocation failed (deferred NMS)"); }
-        hipMemset(e->d_count_alt, 0, B * sizeof(int));
-    }
-
-    // warmupModel analogue (onnx_engine.cpp:919-954): constant-128 frames of model size
+    // warmupModel analogue (onnx_engine.cpp:919-954): constant-128 frames of model size through the single-frame path, then the
+    // throughput path at max_batch.  Both go through the normal entry points' machinery (gate, capture, replay).
     if (cfg->warmup_runs > 0) {
         const size_t fb = (size_t)cfg->model_w * cfg->model_h * 3;
         std::vector<uint8_t> grey(fb, 128);
         std::vector<zly_det> dets((size_t)cfg->max_dets);
-        for (int i = 0; i < cfg->warmup_runs; ++i) {
+        for (int i = 0; i < cfg->warmup_runs && rc == ZLY_OK; ++i) {
             int32_t nd = 0;
             rc = zly_detect(e, grey.data(), fb, cfg->model_w, cfg->model_h, dets.data(), cfg->max_dets, &nd);
-            if (rc != ZLY_OK) { std::string m = g_last_error; destroy_engine(e); return fail(rc, "warm-up failed: " + m); }
         }
+        if (rc == ZLY_OK && cfg->max_batch > 1) rc = warm_batch(e, cfg->max_batch);
+        if (rc != ZLY_OK) { std::string m = g_last_error; destroy_engine(e); return fail(rc, "warm-up failed: " + m); }
         with_stats(e, [](zly_stats& st) { st = zly_stats{}; });
         e->sample_ctr = 0; e->t_pending = false;
     }
@@ -1527,14 +1701,14 @@ int32_t zly_create(const zly_config* cfg, zly_engine** out)
 int32_t zly_destroy(zly_engine* e)
 {
     if (!e) return ZLY_OK;
-    destroy_engine(e);
+    const hipError_t r = destroy_engine(e);
+    if (r != hipSuccess) return fail(ZLY_ERR_SYSTEM, std::string("zly_destroy: ") + hipGetErrorString(r));
     return ZLY_OK;
 }
 
 static int detect_host_locked(zly_engine* e, int32_t n, const uint8_t* const* bgr, const size_t* nbytes,
                               const int32_t* w, const int32_t* h, zly_det* out, int32_t cap, int32_t* n_out)
 {
-    std::unique_lock<std::mutex> gl(g_enqueue_mu);
     HIP_TRY(hipSetDevice(e->dev), ZLY_ERR_SYSTEM);
     std::vector<size_t> offs((size_t)n);
     size_t total = 0;
@@ -1547,10 +1721,16 @@ static int detect_host_locked(zly_engine* e, int32_t n, const uint8_t* const* bg
         offs[(size_t)i] = total;
         total += (nbytes[i] + 15) / 16 * 16;
     }
-    int rc = ensure_stage(e, total);
-    if (rc != ZLY_OK) return rc;
+    int rc = ZLY_OK;
+    if (total > e->stage_bytes) {                                        // growth beyond what zly_create staged (frames larger than the model input): an allocation, alone in the process
+        ExclusiveGate x;
+        rc = ensure_stage(e, total);
+        if (rc != ZLY_OK) return rc;
+    }
+    // waiting for the device and the host copy are not enqueue sections: no gate is held across them (other engines keep enqueuing)
     HIP_TRY(hipStreamSynchronize(e->stream), ZLY_ERR_INFERENCE);        // pinned staging is reused call to call
     for (int i = 0; i < n; ++i) memcpy(e->h_stage + offs[(size_t)i], bgr[i], nbytes[i]);
+    SharedGate gl;
     HIP_TRY(hipMemcpyAsync(e->d_stage, e->h_stage, total, hipMemcpyHostToDevice, e->stream), ZLY_ERR_INFERENCE);
     rc = set_desc(e, n, w, h, offs.data(), e->stream);
     if (rc != ZLY_OK) return rc;
@@ -1558,7 +1738,7 @@ static int detect_host_locked(zly_engine* e, int32_t n, const uint8_t* const* bg
     if (rc != ZLY_OK) { with_stats(e, [](zly_stats& st) { st.inference_errors++; }); return rc; }
     const size_t sb = slab_bytes_of(e);
     HIP_TRY(hipMemcpyAsync(e->h_slabs, e->d_slabs, sb * (size_t)n, hipMemcpyDeviceToHost, e->stream), ZLY_ERR_INFERENCE);
-    gl.unlock();                                                         // waiting for the device is not an enqueue section
+    gl.release();                                                        // waiting for the device is not an enqueue section
     HIP_TRY(hipStreamSynchronize(e->stream), ZLY_ERR_INFERENCE);
     const uint64_t ts = now_ms();                                        // onnx_engine.cpp:813-815
     for (int i = 0; i < n; ++i) {
@@ -1624,7 +1804,7 @@ int32_t zly_detect_device(zly_engine* e, int32_t n, const void* d_frames, int32_
     if (!d_frames || w <= 0 || h <= 0) return fail(ZLY_ERR_INVALID_INPUT, "bad frame pointer or size");
     if (n < 1 || n > e->cfg.max_batch) return fail(ZLY_ERR_INVALID_ARGUMENT, "batch size out of range");
     std::lock_guard<std::mutex> lk(e->mu);
-    std::lock_guard<std::mutex> gl(g_enqueue_mu);
+    SharedGate gl;
     HIP_TRY(hipSetDevice(e->dev), ZLY_ERR_SYSTEM);
     hipStream_t s = stream ? (hipStream_t)stream : e->stream;
     std::vector<int32_t> ws((size_t)n, w), hs((size_t)n, h);
@@ -1644,13 +1824,14 @@ int32_t zly_detect_device(zly_engine* e, int32_t n, const void* d_frames, int32_
 int32_t zly_join(zly_engine* e, void* stream, int32_t lag)
 {
     if (!e) return fail(ZLY_ERR_NOT_INITIALIZED, "Engine not running");
-    if (lag < 0) return fail(ZLY_ERR_INVALID_ARGUMENT, "lag must be >= 0");
+    // completion events are kept for the last two calls only: a larger lag could not be ordered and used to return ZLY_OK without ordering anything
+    if (lag < 0 || lag > 1) return fail(ZLY_ERR_INVALID_ARGUMENT, "lag must be 0 or 1");
     std::lock_guard<std::mutex> lk(e->mu);
-    std::lock_guard<std::mutex> gl(g_enqueue_mu);
+    SharedGate gl;
     HIP_TRY(hipSetDevice(e->dev), ZLY_ERR_SYSTEM);
     hipStream_t s = stream ? (hipStream_t)stream : e->stream;
     // every call but the last `lag`: calls are stream-ordered among themselves, so waiting for call (last - lag) covers all earlier ones
-    if (lag <= 1 && e->call_seq > (uint64_t)lag)
+    if (e->call_seq > (uint64_t)lag)
         HIP_TRY(hipStreamWaitEvent(s, e->ev_call[(e->call_seq - 1 - (uint64_t)lag) & 1], 0), ZLY_ERR_INFERENCE);
     return join_nms(e, s, lag);
 }
@@ -1675,7 +1856,7 @@ int32_t zly_read_slabs(zly_engine* e, int32_t n, void* host_slabs)
     std::lock_guard<std::mutex> lk(e->mu);
     HIP_TRY(hipSetDevice(e->dev), ZLY_ERR_SYSTEM);
     {
-        std::lock_guard<std::mutex> gl(g_enqueue_mu);
+        SharedGate gl;
         int rcj = join_nms(e, e->stream);
         if (rcj != ZLY_OK) return rcj;
         HIP_TRY(hipMemcpyAsync(host_slabs, e->d_slabs, slab_bytes_of(e) * (size_t)n, hipMemcpyDeviceToHost, e->stream), ZLY_ERR_INFERENCE);
@@ -1691,7 +1872,7 @@ int32_t zly_preprocess(zly_engine* e, const uint8_t* bgr, size_t nbytes, int32_t
     if (!bgr || w <= 0 || h <= 0 || nbytes != (size_t)w * (size_t)h * 3u)
         return fail(ZLY_ERR_INVALID_INPUT, "Invalid image data size: expected " + std::to_string((size_t)(w > 0 ? w : 0) * (size_t)(h > 0 ? h : 0) * 3u) + ", got " + std::to_string(nbytes));
     std::lock_guard<std::mutex> lk(e->mu);
-    std::lock_guard<std::mutex> gl(g_enqueue_mu);         // parity / debug entry point: allocations and copies, never beside another engine's capture
+    ExclusiveGate gl;                                    // parity / debug entry point: allocations and copies, alone in the process
     HIP_TRY(hipSetDevice(e->dev), ZLY_ERR_SYSTEM);
     int rc = ensure_stage(e, nbytes);
     if (rc != ZLY_OK) return rc;
@@ -1716,11 +1897,15 @@ int32_t zly_forward(zly_engine* e, int32_t n, const float* images_nchw, float* h
     if (!images_nchw || !head_out) return fail(ZLY_ERR_INVALID_ARGUMENT, "null argument");
     if (n < 1 || n > e->cfg.max_batch) return fail(ZLY_ERR_INVALID_ARGUMENT, "batch size out of range");
     std::lock_guard<std::mutex> lk(e->mu);
-    std::lock_guard<std::mutex> gl(g_enqueue_mu);
     HIP_TRY(hipSetDevice(e->dev), ZLY_ERR_SYSTEM);
     const size_t elems = (size_t)n * 3 * e->cfg.model_w * e->cfg.model_h;
-    int rc = ensure_scratch_f32(e, elems);
+    int rc = ZLY_OK;
+    {
+        ExclusiveGate x;                                      // scratch allocation: alone in the process
+        rc = ensure_scratch_f32(e, elems);
+    }
     if (rc != ZLY_OK) return rc;
+    SharedGate gl;
     HIP_TRY(hipMemcpyAsync(e->d_scratch_f32, images_nchw, elems * sizeof(float), hipMemcpyHostToDevice, e->stream), ZLY_ERR_INFERENCE);
     HIP_TRY(launch_nchw_to_nhwc8(e->dtype, e->d_scratch_f32, e->bufs[(size_t)e->in_buf].ptr, n, e->cfg.model_w, e->cfg.model_h, e->stream), ZLY_ERR_INFERENCE);
     // frames are model-sized for the purposes of the (unused) decode that follows
@@ -1741,7 +1926,7 @@ int32_t zly_head_tensor(zly_engine* e, int32_t idx, float* head_out)
     if (!e) return fail(ZLY_ERR_NOT_INITIALIZED, "Engine not running");
     if (!head_out || idx < 0 || idx >= e->cfg.max_batch) return fail(ZLY_ERR_INVALID_ARGUMENT, "bad argument");
     std::lock_guard<std::mutex> lk(e->mu);
-    std::lock_guard<std::mutex> gl(g_enqueue_mu);         // parity / debug entry point: allocations and copies, never beside another engine's capture
+    SharedGate gl;
     HIP_TRY(hipSetDevice(e->dev), ZLY_ERR_SYSTEM);
     if (e->cfg.flags & ZLY_FLAG_NO_HEAD_TENSOR) return fail(ZLY_ERR_INVALID_ARGUMENT, "engine was created with ZLY_FLAG_NO_HEAD_TENSOR: the head tensor is not materialised");
     const size_t per = (4 + (size_t)e->nc) * e->N;
@@ -1757,7 +1942,7 @@ int32_t zly_postprocess(zly_engine* e, const float* head, int32_t num_classes, i
     if (!head || !out || !n_out || num_classes < 1 || num_classes > 1024 || num_boxes < 0 || cap < 1 || img_w <= 0 || img_h <= 0)
         return fail(ZLY_ERR_INVALID_ARGUMENT, "bad argument");
     std::lock_guard<std::mutex> lk(e->mu);
-    std::lock_guard<std::mutex> gl(g_enqueue_mu);         // parity / debug entry point: allocations and copies, never beside another engine's capture
+    ExclusiveGate gl;                                    // parity / debug entry point: allocations and copies, alone in the process
     HIP_TRY(hipSetDevice(e->dev), ZLY_ERR_SYSTEM);
     *n_out = 0;
     if (n_candidates) *n_candidates = 0;
@@ -1801,7 +1986,7 @@ int32_t zly_debug_tap(zly_engine* e, const char* name, int32_t idx, float* out, 
     if (!e) return fail(ZLY_ERR_NOT_INITIALIZED, "Engine not running");
     if (!name || !out || idx < 0 || idx >= e->cfg.max_batch) return fail(ZLY_ERR_INVALID_ARGUMENT, "bad argument");
     std::lock_guard<std::mutex> lk(e->mu);
-    std::lock_guard<std::mutex> gl(g_enqueue_mu);         // parity / debug entry point: allocations and copies, never beside another engine's capture
+    ExclusiveGate gl;                                    // parity / debug entry point: allocations and copies, alone in the process
     HIP_TRY(hipSetDevice(e->dev), ZLY_ERR_SYSTEM);
     int buf = -1, co = 0, C = 0;
     bool f32 = false;
@@ -1886,11 +2071,8 @@ int32_t zly_op_kernel_name(zly_engine* e, int32_t i, int32_t n, char* out, size_
             break;
         }
         if (op.pair && pair_active(e, op, n)) { k = op.pair == 1 ? "bottleneck_pair_kernel<" + std::to_string(op.pair_c) + ">" : "(fused into the previous launch)"; break; }
-        const Buffer& ob = e->bufs[(size_t)op.out.buf];
         const int cin = op.in.C + (op.in2.buf >= 0 ? op.in2.C : 0);
-        ConvLaunch c;
-        conv_pick_config(e->dtype, op.ks, op.stride, cin, op.cout_pad, n, ob.H, ob.W, &c,
-                         op.in2.buf < 0 && op.res.buf < 0 && op.act && !op.out_f32 && op.cout % 32 == 0);
+        const ConvLaunch c = conv_launch_of(e, op, n);
         if (c.lds) k = "conv3x3_lds_kernel<S=" + std::to_string(op.stride) + ",CT=" + std::to_string(c.ct) + ",PT=" + std::to_string(c.pt) + (c.wres ? ",wres>" : ">");
         else if (c.stream) k = "conv1x1_stream_kernel<CT=" + std::to_string(c.ct) + ",PT=" + std::to_string(c.pt) + ",NK=" + std::to_string((cin + 31) / 32) + ">";
         else k = std::string("conv_igemm_kernel<") + (op.ks == 1 ? (op.in2.buf >= 0 ? "1x1 dual-source" : "1x1") : (c.fastk ? "3x3" : "3x3 generic-K")) +
@@ -1903,12 +2085,71 @@ int32_t zly_op_kernel_name(zly_engine* e, int32_t i, int32_t n, char* out, size_
     return ZLY_OK;
 }
 
+int32_t zly_launch_info_at(zly_engine* e, int32_t i, int32_t n, zly_launch_info* out)
+{
+    if (!e || !out || i < 0 || i >= (int32_t)e->ops.size() || n < 1 || n > e->cfg.max_batch) return fail(ZLY_ERR_INVALID_ARGUMENT, "bad argument");
+    std::lock_guard<std::mutex> lk(e->mu);
+    memset(out, 0, sizeof *out);
+    const int nops = (int)e->ops.size();
+    out->covered_by = op_covered_by(e, i, n);
+    if (out->covered_by != i) return ZLY_OK;
+    std::vector<char> in_group((size_t)nops, 0);
+    for (int j = 0; j < nops; ++j) in_group[(size_t)j] = op_covered_by(e, j, n) == i ? 1 : 0;
+    // channel maps per buffer: written inside the group / read outside the group
+    std::map<int, std::vector<char>> written_in, read_out, counted_in, counted_out;
+    auto chan = [&](std::map<int, std::vector<char>>& m, int buf) -> std::vector<char>& {
+        std::vector<char>& v = m[buf];
+        if (v.empty()) v.assign((size_t)e->bufs[(size_t)buf].C + 64, 0);
+        return v;
+    };
+    std::vector<IoView> io;
+    for (int j = 0; j < nops; ++j) {
+        io.clear();
+        if (in_group[(size_t)j]) { op_writes(e, e->ops[(size_t)j], &io); for (const IoView& v : io) for (int c = 0; c < v.C; ++c) chan(written_in, v.buf)[(size_t)(v.co + c)] = 1; }
+        else { op_reads(e, e->ops[(size_t)j], &io); for (const IoView& v : io) for (int c = 0; c < v.C; ++c) chan(read_out, v.buf)[(size_t)(v.co + c)] = 1; }
+    }
+    double ext_in = 0, ext_out = 0, wbytes = 0;
+    for (int j = 0; j < nops; ++j) {
+        if (!in_group[(size_t)j]) continue;
+        const Op& op = e->ops[(size_t)j];
+        out->n_ops++;
+        out->flops_per_frame += op.flops;
+        out->bytes_unfused_per_frame += op.bytes;
+        wbytes += op.wbytes;
+        if (op.kind == OP_PREPROCESS) ext_in += (double)e->cfg.model_w * e->cfg.model_h * 3;          // the u8 frame (model-sized requests)
+        if (op.kind == OP_HEAD && !(e->cfg.flags & ZLY_FLAG_NO_HEAD_TENSOR)) ext_out += (double)op.head.lv[op.level].hw * (4 + e->nc) * 4.0;
+        io.clear(); op_reads(e, op, &io);
+        for (const IoView& v : io) {
+            int cext = 0;
+            for (int c = 0; c < v.C; ++c) {
+                const size_t ch = (size_t)(v.co + c);
+                if (chan(written_in, v.buf)[ch] || chan(counted_in, v.buf)[ch]) continue;
+                chan(counted_in, v.buf)[ch] = 1; ++cext;
+            }
+            ext_in += v.px * cext * (double)e->esz * v.scale;
+        }
+        io.clear(); op_writes(e, op, &io);
+        for (const IoView& v : io) {
+            int cext = 0;
+            for (int c = 0; c < v.C; ++c) {
+                const size_t ch = (size_t)(v.co + c);
+                if (!chan(read_out, v.buf)[ch] || chan(counted_out, v.buf)[ch]) continue;
+                chan(counted_out, v.buf)[ch] = 1; ++cext;
+            }
+            ext_out += v.px * cext * (double)e->esz * v.scale;
+        }
+    }
+    out->bytes_fused_per_frame = ext_in + ext_out + wbytes;
+    out->weight_bytes = wbytes;
+    return ZLY_OK;
+}
+
 int32_t zly_profile_ops(zly_engine* e, int32_t n, const void* d_frames, int32_t w, int32_t h, int32_t reps, float* ms_out)
 {
     if (!e) return fail(ZLY_ERR_NOT_INITIALIZED, "Engine not running");
     if (!d_frames || !ms_out || reps < 1 || n < 1 || n > e->cfg.max_batch) return fail(ZLY_ERR_INVALID_ARGUMENT, "bad argument");
     std::lock_guard<std::mutex> lk(e->mu);
-    std::lock_guard<std::mutex> gl(g_enqueue_mu);
+    ExclusiveGate gl;
     HIP_TRY(hipSetDevice(e->dev), ZLY_ERR_SYSTEM);
     std::vector<int32_t> ws((size_t)n, w), hs((size_t)n, h);
     std::vector<size_t> offs((size_t)n);

@@ -90,6 +90,11 @@ Result<void> HipInferenceEngine::initialize()
         next_emit_ = 0;
     }
     running_ = true;
+    {
+        std::lock_guard<std::mutex> lk(reap_mutex_);
+        reap_stop_ = false;
+    }
+    reaper_ = std::thread(&HipInferenceEngine::reaperLoop, this);
     completer_ = std::thread(&HipInferenceEngine::completionLoop, this);
     if (envInt("ZLY_MODEL_WATCH_MS", 10000) > 0) monitor_ = std::thread(&HipInferenceEngine::monitorLoop, this);
     return Result<void>::ok();
@@ -143,13 +148,39 @@ Result<void> HipInferenceEngine::reloadModel()
         std::lock_guard<std::mutex> lk(engines_mutex_);
         engines_.swap(fresh);
     }
-    fresh.clear();                                              // old engines go when their last pending request is done
+    for (auto& h : fresh) retire(std::move(h));                 // old engines go -- on the reaper thread -- when their last pending request is done
+    fresh.clear();
     {
         std::lock_guard<std::mutex> lk(stats_mutex_);
         model_hash_ = hash;
     }
     model_version_++;
     return Result<void>::ok();
+}
+
+void HipInferenceEngine::retire(std::shared_ptr<EngineHandle>&& h)
+{
+    if (!h) return;
+    const bool last = h.use_count() == 1;
+    {
+        std::lock_guard<std::mutex> lk(reap_mutex_);
+        retired_.push_back(std::move(h));
+    }
+    if (last) reap_cv_.notify_one();                            // otherwise the reaper's next periodic pass drops it
+}
+
+void HipInferenceEngine::reaperLoop()
+{
+    std::vector<std::shared_ptr<EngineHandle>> batch;
+    while (true) {
+        {
+            std::unique_lock<std::mutex> lk(reap_mutex_);
+            reap_cv_.wait_for(lk, std::chrono::milliseconds(50), [&] { return reap_stop_ || !retired_.empty(); });
+            batch.swap(retired_);
+            if (batch.empty() && reap_stop_) return;
+        }
+        batch.clear();                                          // the last reference of a replaced engine: zly_destroy runs here
+    }
 }
 
 void HipInferenceEngine::monitorLoop()
@@ -189,6 +220,12 @@ Result<void> HipInferenceEngine::shutdown()
     }
     if (completer_.joinable()) completer_.join();               // hands over what is already on the device, then stops
     if (monitor_.joinable()) monitor_.join();
+    {
+        std::lock_guard<std::mutex> lk(reap_mutex_);
+        reap_stop_ = true;
+    }
+    reap_cv_.notify_all();
+    if (reaper_.joinable()) reaper_.join();
     {
         std::lock_guard<std::mutex> lk(queue_mutex_);
         dropped_frames_ += pending_.size();
@@ -282,7 +319,7 @@ void HipInferenceEngine::completionLoop()
             } else {
                 inference_errors_++;
             }
-            p.engine.reset();                                    // an engine replaced by a reload goes with its last request
+            retire(std::move(p.engine));                         // an engine replaced by a reload goes with its last request -- on the reaper thread
         }
         // hand over in submission order
         std::vector<Done> ready;

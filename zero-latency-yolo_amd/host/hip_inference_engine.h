@@ -71,6 +71,8 @@ private:
 
     void completionLoop();
     void monitorLoop();
+    void reaperLoop();
+    void retire(std::shared_ptr<EngineHandle>&& h);         // drop a reference on the reaper thread (the last one destroys the engine there)
     std::shared_ptr<EngineHandle> createEngineOn(int device, int32_t* rc, std::string* msg) const;
 
     ServerConfig config_;
@@ -80,7 +82,13 @@ private:
     std::vector<std::shared_ptr<EngineHandle>> engines_;   // one per GPU
     int first_device_ = 0;
     int engines_per_gpu_ = 1;
-    std::thread monitor_, completer_;
+    std::thread monitor_, completer_, reaper_;
+    // Engines replaced by a hot reload are destroyed on the reaper thread: zly_destroy drains the engine's streams and takes the process-wide
+    // exclusive gate, which must never stall callback delivery (the completion thread) or a submitting thread.
+    std::mutex reap_mutex_;
+    std::condition_variable reap_cv_;
+    std::vector<std::shared_ptr<EngineHandle>> retired_;
+    bool reap_stop_ = false;
     std::mutex reload_mutex_;                              // one reload at a time
     std::atomic<uint32_t> model_version_{1};
     std::string model_hash_;                               // guarded by stats_mutex_

@@ -2,7 +2,7 @@
 // detections in host memory", config 3: >= 8 submitting host threads), measured natively so that no interpreter sits
 // between the threads and the C ABI.  bench.py runs it as a child process and embeds its JSON line.
 //
-//   zly_h2h_bench <weights.zlyw> <cabi|plugin> <threads> <seconds> <max_batch> [engines [w h]]
+//   zly_h2h_bench <weights.zlyw> <cabi|plugin|lone> <threads> <seconds> <max_batch> [engines [w h]]
 //
 // engines > 1: that many engine instances on the GPU (ZLY_FLAG_SINGLE_CHAIN), submitting thread t feeds engine t % engines; their
 // batches overlap on the device (bench.py --engines)
@@ -12,6 +12,9 @@
 //         (onnx_engine.cpp:223-261, 355-364).
 // plugin: the same load through HipInferenceEngine::submitInference / InferenceCallback, i.e. what the reference's
 //         NetworkServer would drive (network_server.cpp:184-224, 243-283).
+// lone  : the latency a single client of the server sees: ONE thread, HipInferenceEngine::submitInference of one frame, wait for its
+//         InferenceCallback, submit the next (reference: one client's frame through runInference, onnx_engine.cpp:518-646); p50 / p99 of
+//         submit -> callback.  The pipelined path serves a lone frame at once (no batching window) by replaying the batch-1 graph.
 // Frames are u8 BGR noise in ordinary (pageable) host memory, 4 distinct frames per thread.
 #include "zly_compat.hpp"
 #include "hip_inference_engine.h"
@@ -183,6 +186,39 @@ int main(int argc, char** argv)
     });
     auto init = engine->initialize();
     if (init.hasError()) { std::fprintf(stderr, "initialize: %s\n", init.error().toString().c_str()); return 3; }
+    if (mode == "lone") {
+        InferenceRequest r;
+        r.client_id = 7; r.width = (uint16_t)W; r.height = (uint16_t)H;
+        Lat sub;                                                     // time inside submitInference itself (the copy into the pinned ring)
+        const auto run_until = [&](double secs_) {
+            const auto end = Clock::now() + std::chrono::duration<double>(secs_);
+            uint32_t k = 0;
+            while (Clock::now() < end) {
+                r.data = frames[0][k & 3];
+                r.frame_id = k++;
+                const uint64_t want = completed.load() + 1;
+                const auto ts = Clock::now();
+                r.timestamp = (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(ts.time_since_epoch()).count();
+                if (engine->submitInference(r).hasError()) { errors++; return; }
+                sub.add(secs(ts, Clock::now()) * 1e3);
+                while (completed.load() < want) { /* spin: the client's own receive loop is not what is measured */ }
+            }
+        };
+        run_until(0.3);
+        { std::lock_guard<std::mutex> lk(lat_mu); lat.ms.clear(); }
+        sub.ms.clear();
+        t0 = Clock::now();
+        run_until(seconds);
+        t1 = Clock::now();
+        auto status = engine->getStatus();
+        engine->shutdown();
+        std::lock_guard<std::mutex> lk(lat_mu);
+        std::printf("{\"mode\":\"lone\",\"engines\":%d,\"max_batch\":%d,\"frame\":\"%dx%d\",\"seconds\":%.3f,\"frames\":%zu,\"frames_per_sec\":%.1f,"
+                    "\"p50_ms\":%.4f,\"p90_ms\":%.4f,\"p99_ms\":%.4f,\"submit_p50_ms\":%.4f,\"errors\":%llu,\"batches\":%s}\n",
+                    E, max_batch, W, H, secs(t0, t1), lat.ms.size(), (double)lat.ms.size() / secs(t0, t1), lat.pct(0.5), lat.pct(0.9), lat.pct(0.99), sub.pct(0.5),
+                    (unsigned long long)errors.load(), status["batches"].c_str());
+        return errors ? 4 : 0;
+    }
     std::vector<std::thread> subs;
     for (int t = 0; t < T; ++t)
         subs.emplace_back([&, t] {

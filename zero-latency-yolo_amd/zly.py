@@ -37,7 +37,7 @@ SYMBOLS = [
     "zly_default_config", "zly_create", "zly_destroy", "zly_last_error", "zly_version",
     "zly_detect", "zly_detect_batch", "zly_submit", "zly_poll", "zly_wait", "zly_detect_device", "zly_slab_bytes", "zly_read_slabs", "zly_sync", "zly_join",
     "zly_preprocess", "zly_forward", "zly_head_tensor", "zly_postprocess", "zly_debug_tap",
-    "zly_num_classes", "zly_weights_fp8", "zly_num_anchors", "zly_num_ops", "zly_op_info_at", "zly_op_kernel_name", "zly_profile_ops", "zly_get_stats",
+    "zly_num_classes", "zly_weights_fp8", "zly_num_anchors", "zly_num_ops", "zly_op_info_at", "zly_launch_info_at", "zly_op_kernel_name", "zly_profile_ops", "zly_get_stats",
 ]
 
 DET_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("w", "<f4"), ("h", "<f4"), ("confidence", "<f4"),
@@ -64,6 +64,11 @@ class Stats(C.Structure):
 class OpInfo(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("kind", C.c_int32), ("pad_", C.c_int32),
                 ("flops_per_frame", C.c_double), ("bytes_per_frame", C.c_double)]
+
+
+class LaunchInfo(C.Structure):
+    _fields_ = [("covered_by", C.c_int32), ("n_ops", C.c_int32), ("flops_per_frame", C.c_double),
+                ("bytes_unfused_per_frame", C.c_double), ("bytes_fused_per_frame", C.c_double), ("weight_bytes", C.c_double)]
 
 
 class ZlyError(RuntimeError):
@@ -112,6 +117,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.zly_weights_fp8.argtypes = [vp]; lib.zly_weights_fp8.restype = i32
     lib.zly_num_ops.argtypes = [vp]; lib.zly_num_ops.restype = i32
     lib.zly_op_info_at.argtypes = [vp, i32, C.POINTER(OpInfo)]; lib.zly_op_info_at.restype = i32
+    lib.zly_launch_info_at.argtypes = [vp, i32, i32, C.POINTER(LaunchInfo)]; lib.zly_launch_info_at.restype = i32
     lib.zly_op_kernel_name.argtypes = [vp, i32, i32, C.c_char_p, sz]; lib.zly_op_kernel_name.restype = i32
     lib.zly_profile_ops.argtypes = [vp, i32, vp, i32, i32, i32, vp]; lib.zly_profile_ops.restype = i32
     lib.zly_get_stats.argtypes = [vp, C.POINTER(Stats)]; lib.zly_get_stats.restype = i32
@@ -273,6 +279,15 @@ class Engine:
             info = OpInfo()
             _check(self.lib, self.lib.zly_op_info_at(self.h, i, C.byref(info)))
             out.append(dict(name=info.name.decode(), kind=info.kind, flops=info.flops_per_frame, bytes=info.bytes_per_frame))
+        return out
+
+    def launches(self, n: int) -> List[dict]:
+        """launch groups at batch size n: one record per op (covered_by != index: the op runs inside another op's launch)"""
+        out = []
+        for i in range(self.lib.zly_num_ops(self.h)):
+            li = LaunchInfo()
+            _check(self.lib, self.lib.zly_launch_info_at(self.h, i, n, C.byref(li)))
+            out.append({k: getattr(li, k) for k, _ in LaunchInfo._fields_})
         return out
 
     def op_kernels(self, n: int) -> List[str]:
