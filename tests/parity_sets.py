@@ -63,22 +63,40 @@ def measured_bands(ref_head, other_head, conf=0.5, iou_thr=0.45, margin=2.0, flo
     return clamp(ds), clamp(di)
 
 
-def compare_detection_sets(oracle, ref_head, got, img_w, img_h, conf=0.5, iou_thr=0.45, band=2e-2, min_iou=0.9, band_iou=None):
+def compare_detection_sets(oracle, ref_head, got, img_w, img_h, conf=0.5, iou_thr=0.45, band=2e-2, min_iou=0.9, band_iou=None, got_head=None, floor=1e-3):
     """oracle: tests/oracle_lib.Oracle; ref_head: fp32 oracle head tensor [4+nc][N] of the frame; got: the engine's
-    detections (structured zly_det array); band: half-width of the score flip band (also the confidence tolerance of matched
-    detections); band_iou: half-width of the IoU flip band (default: band) -- SURVEY 8c's 2e-2, or this frame's measured_bands().
+    detections (structured zly_det array); band: confidence tolerance of matched detections and -- without got_head -- the
+    half-width of the score flip band; band_iou: half-width of the IoU flip band (default: band).
+    got_head: the ENGINE's own head tensor of the frame (the very values its Detect kernel thresholded; the GPU tests assert
+    separately that it is within tolerance of the oracle's).  With it, a component is ambiguous only where a threshold decision
+    REALLY differs between the two tensors -- a score on different sides of conf, a different arg-max class, an IoU on
+    different sides of iou_thr, a different order of two overlapping same-class boxes -- or sits within `floor` of its
+    threshold; every other component is compared exactly.  Without it, everything within the bands of a threshold is skipped.
     Returns (n_compared, n_skipped, errors): detections compared exactly, oracle detections skipped inside ambiguous
     components, list of error strings (empty = parity holds)."""
     want = oracle.postprocess(ref_head, img_w, img_h, conf, iou_thr)
     errors = []
     band_iou = band if band_iou is None else band_iou
-    # nodes: (anchor, class) pairs the engine may legitimately report -- the anchor's best class, plus every class within
-    # `band` of it, when they score >= conf - band (postProcess keeps the arg-max class only, onnx_engine.cpp:787-799)
     ref_head = np.asarray(ref_head, dtype=np.float32)
     sc = ref_head[4:]
     top = sc.max(0)
-    cls_i, anc_i = np.nonzero((sc >= np.maximum(top - band, conf - band)[None]) & (top >= conf - band)[None])
-    per_anchor = np.bincount(anc_i, minlength=sc.shape[1])
+    if got_head is not None:
+        # node set: the best class of an anchor in EITHER tensor, when it reaches conf - floor in either
+        gh = np.asarray(got_head, dtype=np.float32)
+        gsc = gh[4:]
+        gtop = gsc.max(0)
+        ca, cg = sc.argmax(0), gsc.argmax(0)
+        live = np.nonzero((top >= conf - floor) | (gtop >= conf - floor))[0]
+        pairs = sorted(set((int(ca[a]), int(a)) for a in live) | set((int(cg[a]), int(a)) for a in live))
+        cls_i = np.array([p[0] for p in pairs], dtype=np.int64)
+        anc_i = np.array([p[1] for p in pairs], dtype=np.int64)
+        s_band, i_band = floor, floor
+    else:
+        # nodes: (anchor, class) pairs the engine may legitimately report -- the anchor's best class, plus every class within
+        # `band` of it, when they score >= conf - band (postProcess keeps the arg-max class only, onnx_engine.cpp:787-799)
+        cls_i, anc_i = np.nonzero((sc >= np.maximum(top - band, conf - band)[None]) & (top >= conf - band)[None])
+        s_band, i_band = band, band_iou
+    per_anchor = np.bincount(anc_i, minlength=sc.shape[1]) if len(anc_i) else np.zeros(sc.shape[1], dtype=np.int64)
     nodes = np.zeros(len(anc_i), dtype=[("x", "<f8"), ("y", "<f8"), ("w", "<f8"), ("h", "<f8"), ("confidence", "<f8"), ("class_id", "<i4")])
     nodes["x"] = ref_head[0, anc_i].astype(np.float64) / img_w; nodes["y"] = ref_head[1, anc_i].astype(np.float64) / img_h
     nodes["w"] = ref_head[2, anc_i].astype(np.float64) / img_w; nodes["h"] = ref_head[3, anc_i].astype(np.float64) / img_h
@@ -93,18 +111,32 @@ def compare_detection_sets(oracle, ref_head, got, img_w, img_h, conf=0.5, iou_th
             i = comp[i]
         return i
 
-    amb_node = (np.abs(nodes["confidence"] - conf) <= band) | (per_anchor[anc_i] > 1) if n else np.zeros(0, bool)
+    amb_node = (np.abs(nodes["confidence"] - conf) <= s_band) | (per_anchor[anc_i] > 1) if n else np.zeros(0, bool)
     amb_edges = []
+    if n and got_head is not None:
+        gconf = gsc[cls_i, anc_i].astype(np.float64)
+        amb_node = amb_node | ((nodes["confidence"] >= conf) != (gconf >= conf))
+        gb = np.stack([gh[0, anc_i] / img_w, gh[1, anc_i] / img_h, gh[2, anc_i] / img_w, gh[3, anc_i] / img_h], 1).astype(np.float64)
     if n:
         iou = _iou_matrix(nb, nb)
         same = nodes["class_id"][:, None] == nodes["class_id"][None]
-        ii, jj = np.nonzero(np.triu(same & (iou >= iou_thr - band_iou), 1))
+        if got_head is not None:
+            giou = _iou_matrix(gb, gb)
+            near = same & ((iou >= iou_thr - i_band) | (giou >= iou_thr - i_band))
+        else:
+            near = same & (iou >= iou_thr - i_band)
+        ii, jj = np.nonzero(np.triu(near, 1))
         for i, j in zip(ii, jj):
             ri, rj = find(i), find(j)
             if ri != rj:
                 comp[ri] = rj
-            if abs(iou[i, j] - iou_thr) <= band_iou:
+            if abs(iou[i, j] - iou_thr) <= i_band:
                 amb_edges.append(i)
+            elif got_head is not None:
+                if (iou[i, j] > iou_thr) != (giou[i, j] > iou_thr):
+                    amb_edges.append(i)                 # this suppression really differs between the two tensors
+                elif (nodes["confidence"][i] > nodes["confidence"][j]) != (gconf[i] > gconf[j]) or nodes["confidence"][i] == nodes["confidence"][j]:
+                    amb_edges.append(i)                 # the greedy order of the two really differs
             elif abs(float(nodes["confidence"][i]) - float(nodes["confidence"][j])) <= band:
                 # the greedy order of i and j may swap: harmless unless they differ in which same-class boxes they suppress
                 si, sj = same[i] & (iou[i] > iou_thr), same[j] & (iou[j] > iou_thr)

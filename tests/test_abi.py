@@ -34,6 +34,24 @@ def test_detection_layout_matches_reference_types_h():
     assert zly.SLAB_HDR_DTYPE.itemsize == 16
 
 
+REFERENCE = "/root/reference"
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REFERENCE, "src", "common", "types.h")), reason="build container only: the reference tree is not on the GPU box")
+def test_detection_layout_against_the_reference_header_itself():
+    """tests/cpp/abi_vs_reference_types.cpp includes the reference's own src/common/types.h (read where it lies, never copied) and
+    static_asserts sizeof / alignof / offsetof of zero_latency::Detection against zly_det: the compiler, not a table of numbers."""
+    import subprocess
+    for tu in ("abi_vs_reference_types.cpp", "abi_vs_reference_result.cpp"):       # result.h: the return codes against zero_latency::ErrorCode
+        src = os.path.join(ROOT, "tests", "cpp", tu)
+        r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I", os.path.join(REFERENCE, "src", "common"), "-I", os.path.join(ROOT, "include"), src],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, (tu, r.stderr)
+    # the plugin's compat header re-declares the same record (the reference's headers do not compile as a whole): same layout as zly_det
+    compat = open(os.path.join(ROOT, "zero-latency-yolo_amd", "host", "hip_inference_engine.cpp")).read()
+    assert "static_assert(sizeof(zly_det) == sizeof(Detection)" in compat
+
+
 def test_error_codes_match_reference_result_h():
     h = _header()
     for name, val in (("ZLY_ERR_NOT_INITIALIZED", 3), ("ZLY_ERR_INFERENCE", 200), ("ZLY_ERR_MODEL_NOT_FOUND", 201),

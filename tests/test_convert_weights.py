@@ -138,3 +138,39 @@ def test_onnx_reader_rejects_garbage(tmp_path):
     p.write_bytes(ow._ld(7, ow._ld(5, ow._vi(1, 4) + ow._vi(2, 1) + ow._ld(9, b"\0" * 8) + ow._ld(8, b"w"))))   # 2 floats for dims [4]
     with pytest.raises(ValueError, match="elements"):
         onnx_min.read_onnx(str(p))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("named", [True, False])
+def test_converted_onnx_runs_on_the_engine(tmp_path, named):
+    """SURVEY 8f rank 3 end to end on the GPU: an ONNX file laid out like `yolo export format=onnx` writes it (reference
+    start.sh:122-132: BN fused, Conv + Sigmoid + Mul nodes, initializers named by module path or anonymised) ->
+    tools/convert_weights.py -> .zlyw -> libzly.so.  The HIP engine's head tensor must match the CPU oracle evaluated on the
+    ORIGINAL tensors (the ones that went into the ONNX file, never through the converter): fp32 engine to SURVEY 8c's fp32
+    tolerance, bf16 engine to the bf16 tolerance, and detect() must equal the oracle's post-processing of the engine's head."""
+    import yolov8_ref
+    import zly
+    from oracle_lib import Oracle, det_fields_equal
+    spec = zm.build_spec("n", 80)
+    weights = zm.synth_weights(spec, seed=33)                       # calibrated synthetic weights (the bf16 tolerance presumes them), a seed of their own
+    path = _fused_onnx(tmp_path, spec, weights, named, styles=("raw", "float_data", "packed_dims"))
+    out = str(tmp_path / "converted.zlyw")
+    assert cw.main(["--onnx", path, "--out", out]) == 0
+    meta = dict(nc=spec.nc, reg_max=spec.reg_max, ch=spec.ch, n_c2f=spec.n_c2f, convs=spec.convs)
+    ref = yolov8_ref.YoloV8Ref(meta, weights, "fp32")              # the original tensors
+    oracle = Oracle()
+    frames = zm.synth_frames(2, 416, 416, seed=44, rects=False)
+    x = np.stack([oracle.preprocess(f, 416, 416)[1] for f in frames])
+    want = ref.forward(torch.from_numpy(x)).numpy()
+    e32 = zly.Engine(out, dtype=zly.DTYPE_FP32, max_batch=2, max_dets=256, warmup_runs=0)
+    got = e32.forward(x)
+    assert np.abs(got[:, :4] - want[:, :4]).max() <= 1e-3 and np.abs(got[:, 4:] - want[:, 4:]).max() <= 1e-4
+    e32.close()
+    e16 = zly.Engine(out, dtype=zly.DTYPE_BF16, max_batch=2, max_dets=256, warmup_runs=1)
+    for i, f in enumerate(frames):
+        dets, n = e16.detect(f, cap=256)
+        head = e16.head_tensor(0)
+        assert np.abs(head[:4] - want[i, :4]).max() <= 1.5 and np.abs(head[4:] - want[i, 4:]).max() <= 2e-2
+        own = oracle.postprocess(head, 416, 416)
+        assert n == len(own) and det_fields_equal(dets, own[:256])
+    e16.close()

@@ -29,7 +29,12 @@ FP32_BOX_TOL = 1e-3      # px
 FP32_SCORE_TOL = 1e-4
 BF16_BOX_MAX, BF16_SCORE_MAX = 1.5, 2e-2      # px @416 / absolute
 BF16_BOX_RMS, BF16_SCORE_RMS = 0.2, 2e-3      # ~4x the noise floor of bf16 itself on this model
-BF16_FLIP_BAND = BF16_SCORE_MAX                # |score - 0.5| below which a candidate may legitimately flip
+BF16_FLIP_BAND = BF16_SCORE_MAX                # confidence tolerance of matched detections (and the flip band where the engine's head is not available)
+# Set-level comparison: at least this share of the oracle's detections must be compared EXACTLY (the rest sit in components where a
+# threshold decision really differs between the engine's own head tensor and the oracle's; tests/parity_sets.py).  The synthetic head's
+# scores are Gaussian-tailed through 0.5 (DESIGN.md section 2 on why a random net cannot be made bimodal), so a band of the full
+# tolerance around the thresholds would skip most detections; the actual flips are few.
+MIN_COMPARED_FRACTION = 0.7
 LAYER_MAX, LAYER_RMS = 2.0 ** -5, 0.03         # conv outputs vs the bf16-rounding oracle: max |d| / max |t|, rms(d) / std(t)
 F6 = ["x", "y", "w", "h", "confidence", "class_id"]
 
@@ -292,10 +297,10 @@ def test_production_kernels_layerwise_vs_oracle(weights_path, oracle, ref_fp32, 
         gh = e.head_tensor(i)
         _assert_bf16_close(gh[None], want16[i][None])
         _assert_bf16_close(gh[None], want32[i][None])
-        c, sk, errors = compare_detection_sets(oracle, want32[i], slabs[i][1], 416, 416, band=BF16_FLIP_BAND)
+        c, sk, errors = compare_detection_sets(oracle, want32[i], slabs[i][1], 416, 416, band=BF16_FLIP_BAND, got_head=gh)
         assert not errors, (i, errors)
         compared += c; skipped += sk
-    assert compared >= 5 * n, (compared, skipped)
+    assert compared >= 5 * n and compared >= MIN_COMPARED_FRACTION * (compared + skipped), (compared, skipped)
     e.close()
 
 
@@ -385,7 +390,9 @@ def test_detect_fp32_matches_full_cpu_pipeline(eng32, oracle, ref_fp32):
                 assert np.abs(dets[k] - want[k]).max() <= FP32_BOX_TOL / 416 * 2
             assert np.abs(dets["confidence"] - want["confidence"]).max() <= FP32_SCORE_TOL
         else:
-            assert abs(n - len(want)) <= 2 and _match(dets, want, oracle.iou, 0.5) or _match(want, dets, oracle.iou, 0.5)
+            # a flip adds or removes a detection: the smaller set must be contained in the larger one, and they differ by at most 2
+            small, large = (dets, want) if n <= len(want) else (want, dets)
+            assert abs(n - len(want)) <= 2 and _match(small, large, oracle.iou, 0.5)
 
 
 def test_detect_bf16_sets_match_fp32_oracle(eng16, oracle, ref_fp32):
@@ -404,10 +411,10 @@ def test_detect_bf16_sets_match_fp32_oracle(eng16, oracle, ref_fp32):
         assert n == len(dets)
         gh = eng16.head_tensor(0)
         assert np.abs(gh[:4] - head[:4]).max() <= BF16_BOX_MAX and np.abs(gh[4:] - head[4:]).max() <= BF16_SCORE_MAX
-        c, sk, errors = compare_detection_sets(oracle, head, dets, f.shape[1], f.shape[0], band=BF16_FLIP_BAND)
+        c, sk, errors = compare_detection_sets(oracle, head, dets, f.shape[1], f.shape[0], band=BF16_FLIP_BAND, got_head=gh)
         assert not errors, errors
         compared += c; skipped += sk
-    assert compared >= 80, (compared, skipped)
+    assert compared >= 80 and compared >= MIN_COMPARED_FRACTION * (compared + skipped), (compared, skipped)
 
 
 def _mixed_frames():
@@ -552,10 +559,13 @@ def test_640x640_fp32_and_bf16(weights_path, oracle, ref_fp32):
         assert n == len(own) and det_fields_equal(dets, own[:512])
     got = e.forward(x)
     _assert_bf16_close(got, want)                                                  # same strides, same pixel tolerance
+    compared = skipped = 0
     for f, head in zip(frames, want):
         dets, n = e.detect(f, cap=512)
-        c, sk, errors = compare_detection_sets(oracle, head, dets, 640, 640, band=BF16_FLIP_BAND)
+        c, sk, errors = compare_detection_sets(oracle, head, dets, 640, 640, band=BF16_FLIP_BAND, got_head=e.head_tensor(0))
         assert not errors and c > 0, errors
+        compared += c; skipped += sk
+    assert compared >= MIN_COMPARED_FRACTION * (compared + skipped), (compared, skipped)
     e.close()
 
 
@@ -900,9 +910,10 @@ def test_fused_c2f_blocks(weights_path, oracle, w, h, n):
         e.tap("model.2.m.0.cv1", 0)                               # stays in LDS even with the dumps
     ref = yolov8_ref.load(weights_path, "bf16")
     ref.forward(torch.from_numpy(x))
+    tf = {name: [e.tap(name, i) for i in range(n)] for name in C2F_TAPS}           # the fused engine's taps, dumps on
     for name in C2F_TAPS:
         for i in range(n):
-            g, t = e.tap(name, i), tp[name][i]
+            g, t = tf[name][i], tp[name][i]
             _assert_layer_close(g, ref.taps[name][i].numpy(), f"{name}[{i}] vs oracle")
             if n >= 16 and not name.startswith("model.2."):
                 assert np.array_equal(g, t), (name, i, float(np.mean(g != t)))
@@ -920,7 +931,7 @@ def test_fused_c2f_blocks(weights_path, oracle, w, h, n):
         with pytest.raises(zly.ZlyError):
             e.tap(name, 0)
     for name in ("model.2.cv2", "model.4.cv1", "model.4.m.0.cv2", "model.4.cv2", "model.15.cv2"):
-        assert np.array_equal(e.tap(name, n - 1), e.tap(name, n - 1))
+        assert np.array_equal(e.tap(name, n - 1), tf[name][n - 1]), name         # == the block outputs of the engine WITH the dumps (first half of this test)
         _assert_layer_close(e.tap(name, n - 1), ref.taps[name][n - 1].numpy(), name)
     e.close()
 

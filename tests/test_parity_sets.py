@@ -23,10 +23,13 @@ def test_bf16_oracle_detections_match_fp32_oracle_detections(oracle, ref_fp32, r
     compared = skipped = 0
     for f, a, b in zip(frames, h32, h16):
         got = oracle.postprocess(b, f.shape[1], f.shape[0])
-        c, s, errors = compare_detection_sets(oracle, a, got, f.shape[1], f.shape[0])
+        c, s, errors = compare_detection_sets(oracle, a, got, f.shape[1], f.shape[0])             # SURVEY's fixed bands: a minority is compared
         assert not errors, errors
-        compared += c; skipped += s
-    assert compared >= 100 and compared >= skipped // 4, (compared, skipped)
+        c2, s2, errors = compare_detection_sets(oracle, a, got, f.shape[1], f.shape[0], got_head=b)  # the decisions that really differ: most are
+        assert not errors, errors
+        assert c + s == c2 + s2 and c2 >= c
+        compared += c2; skipped += s2
+    assert compared >= 100 and compared >= 0.7 * (compared + skipped), (compared, skipped)
 
 
 def test_comparison_catches_shifted_dropped_and_invented_detections(oracle, ref_fp32):
@@ -48,6 +51,11 @@ def test_comparison_catches_shifted_dropped_and_invented_detections(oracle, ref_
         _, _, e2 = compare_detection_sets(oracle, head, np.delete(want, k), 416, 416)
         dropped += bool(e2)
     assert dropped >= c                                 # every exactly-compared detection is missed when absent
+    # ... and the same with the engine-head form of the comparison (here: the oracle's own head, so nothing differs and nothing is skipped)
+    c4, s4, e4 = compare_detection_sets(oracle, head, want, 416, 416, got_head=head)
+    assert not e4 and c4 + s4 == len(want) and c4 >= c
+    _, _, e5 = compare_detection_sets(oracle, head, np.delete(want, 0), 416, 416, got_head=head)
+    assert e5 or s4 > 0
     ghost = want[:1].copy()
     ghost["x"] = 0.5; ghost["y"] = 0.5; ghost["w"] = 0.9; ghost["h"] = 0.9
     _, _, e3 = compare_detection_sets(oracle, head, np.concatenate([want, ghost]), 416, 416)
