@@ -9,6 +9,7 @@ import struct
 
 MAGIC, VERSION, HEADER = 0x59544C5A, 1, 22
 FRAME_DATA, DETECTION_RESULT = 3, 4
+FRAME_CHUNK = 8          # extension (host/zly_wire.hpp): the first value PacketType leaves free (types.h:73-82)
 
 
 def crc16(data: bytes) -> int:
@@ -52,3 +53,33 @@ def check(raw: bytes, expected_type: int):
     tmp = bytearray(raw)
     tmp[20:22] = b"\0\0"
     return 0 if crc16(bytes(tmp[2:])) == checksum else 105
+
+
+def frame_chunk_packets(frame_id, timestamp, width, height, keyframe, pixels: bytes, max_payload, sequence0, packet_ts):
+    """EXTENSION, no reference counterpart (host/zly_wire.hpp FrameChunkPacket): a raw w*h*3 frame as ceil(n / max_payload) packets of
+    type 8; body = the FrameDataPacket fields + chunk index u16, chunk count u16, byte offset u32, then the piece."""
+    assert len(pixels) == width * height * 3 and 0 < max_payload <= 0xFFFF - 25
+    count = (len(pixels) + max_payload - 1) // max_payload
+    out = []
+    for i in range(count):
+        off = i * max_payload
+        body = struct.pack("<IQHHBHHI", frame_id, timestamp, width, height, 1 if keyframe else 0, i, count, off) + pixels[off:off + max_payload]
+        out.append(packet(FRAME_CHUNK, sequence0 + i, packet_ts, body))
+    return out
+
+
+def reassemble(packets):
+    """pieces (any order, duplicates allowed) of ONE frame -> (frame_id, timestamp, width, height, keyframe, pixels) or None while incomplete"""
+    meta, have, buf = None, {}, None
+    for raw in packets:
+        assert check(raw, FRAME_CHUNK) == 0
+        frame_id, ts, w, h, key, idx, count, off = struct.unpack_from("<IQHHBHHI", raw, HEADER)
+        if meta is None:
+            meta, buf = (frame_id, ts, w, h, key, count), bytearray(w * h * 3)
+        assert meta == (frame_id, ts, w, h, key, count)
+        piece = raw[HEADER + 25:]
+        buf[off:off + len(piece)] = piece
+        have[idx] = len(piece)
+    if meta is None or len(have) < meta[5] or sum(have.values()) != len(buf):
+        return None
+    return meta[0], meta[1], meta[2], meta[3], bool(meta[4]), bytes(buf)

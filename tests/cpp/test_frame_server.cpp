@@ -1,7 +1,7 @@
 // test_frame_server.cpp -- bytes in, bytes out around the plugin: FrameDataPacket datagrams -> FrameServer -> HipInferenceEngine
 // -> game-adapter step -> DetectionResultPacket datagrams.   usage: test_frame_server <weights> <packets.bin> <out.bin>
 // packets.bin: u32 count, then {u32 client, u32 nbytes, bytes}.  out.bin: u32 count, then {u32 client, u32 nbytes, bytes}
-// in send order, followed by u64 bad_packets.
+// in send order, followed by u64 bad_packets, u64 reassembled frames.
 #include "zly_frame_server.hpp"
 
 #include <condition_variable>
@@ -49,8 +49,11 @@ int main(int argc, char** argv)
     auto init = engine->initialize();
     if (init.hasError()) { std::fprintf(stderr, "%s\n", init.error().toString().c_str()); return 4; }
     size_t accepted = 0;
-    for (const Pkt& p : pkts)
-        if (server.onPacket(p.client, p.bytes.data(), p.bytes.size()).isOk()) ++accepted;
+    for (const Pkt& p : pkts) {
+        const bool piece = p.bytes.size() > 5 && p.bytes[5] == wire::kTypeFrameChunk;      // a piece of a chunked frame: a result only when its frame completes
+        if (server.onPacket(p.client, p.bytes.data(), p.bytes.size()).isOk() && !piece) ++accepted;
+    }
+    accepted += (size_t)server.reassembledFrames();
     {
         std::unique_lock<std::mutex> lk(mu);
         if (!cv.wait_for(lk, std::chrono::seconds(60), [&] { return sent.size() >= accepted; })) return 6;
@@ -67,5 +70,7 @@ int main(int argc, char** argv)
     }
     const uint64_t bad = server.badPackets();
     out.write(reinterpret_cast<const char*>(&bad), 8);
+    const uint64_t re = server.reassembledFrames();
+    out.write(reinterpret_cast<const char*>(&re), 8);
     return 0;
 }

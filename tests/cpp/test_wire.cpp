@@ -14,6 +14,13 @@ using namespace zero_latency;
 
 static std::vector<uint8_t> slurp(const std::string& p) { std::ifstream f(p, std::ios::binary); return std::vector<uint8_t>(std::istreambuf_iterator<char>(f), {}); }
 static void dump(const std::string& p, const std::vector<uint8_t>& v) { std::ofstream f(p, std::ios::binary); f.write((const char*)v.data(), (std::streamsize)v.size()); }
+static size_t kHeaderOffsetOfChunkOffset() { return 22 + 21; }
+static void refinish(std::vector<uint8_t>& pkt)          // recompute the checksum of a hand-modified packet
+{
+    pkt[20] = 0; pkt[21] = 0;
+    const uint16_t c = wire::crc16(pkt.data() + 2, pkt.size() - 2);
+    std::memcpy(pkt.data() + 20, &c, 2);
+}
 
 int main(int argc, char** argv)
 {
@@ -68,6 +75,63 @@ int main(int argc, char** argv)
         Sha256 e; rep << "sha_empty=" << e.hex() << "\n";
         Sha256 m; const char* s56 = "abcdbcdecdefdefgefghfghighijhijkijkljklmklmnlmnomnopnopq"; m.update(s56, 56); rep << "sha_56=" << m.hex() << "\n";
         rep << "sha_frame_pkt=" << sha256File(dir + "/frame.pkt") << "\nsha_missing=" << sha256File(dir + "/nope") << "\n";
+    }
+    {   // chunked raw frames (extension): <dir>/chunks.bin = u32 count, then {u32 nbytes, packet} in ARRIVAL order (shuffled, with a
+        // duplicate) made by the Python oracle -> reassembled frame -> <dir>/chunks_frame.bin; and the same frame cut here -> <dir>/chunks_out.bin
+        std::vector<uint8_t> blob = slurp(dir + "/chunks.bin");
+        if (blob.size() >= 4) {
+            uint32_t n = 0; std::memcpy(&n, blob.data(), 4);
+            size_t o = 4;
+            wire::FrameAssembler asm_(2);
+            wire::FrameData whole;
+            int completed = 0, errors = 0, complete_at = -1;
+            for (uint32_t i = 0; i < n && o + 4 <= blob.size(); ++i) {
+                uint32_t nb = 0; std::memcpy(&nb, blob.data() + o, 4); o += 4;
+                auto c = wire::parseFrameChunk(blob.data() + o, nb);
+                if (c.hasError()) ++errors;
+                else {
+                    auto d = asm_.add(42, c.value(), &whole);
+                    if (d.hasError()) ++errors;
+                    else if (d.value()) { ++completed; complete_at = (int)i; }
+                }
+                o += nb;
+            }
+            rep << "chunks_completed=" << completed << "\nchunks_errors=" << errors << "\nchunks_complete_at=" << complete_at << "\nchunks_pending=" << asm_.pending(42) << "\n";
+            if (completed) {
+                rep << "chunks_frame_id=" << whole.frame_id << "\nchunks_ts=" << whole.timestamp << "\nchunks_w=" << whole.width << "\nchunks_h=" << whole.height
+                    << "\nchunks_key=" << (whole.keyframe ? 1 : 0) << "\n";
+                dump(dir + "/chunks_frame.bin", whole.data);
+                auto cut = wire::serializeFrameChunks(whole, 60000, 700, 555555);
+                rep << "chunks_serialize=" << static_cast<int>(cut.error().code) << "\n";
+                if (cut.isOk()) {
+                    std::vector<uint8_t> all;
+                    for (const auto& pk : cut.value()) { const uint32_t nb = (uint32_t)pk.size(); all.insert(all.end(), (const uint8_t*)&nb, (const uint8_t*)&nb + 4); all.insert(all.end(), pk.begin(), pk.end()); }
+                    dump(dir + "/chunks_out.bin", all);
+                }
+                // refused: a piece that runs past the frame, a piece that contradicts its frame, an index beyond the count
+                auto one = wire::serializeFrameChunks(whole, 60000, 1, 1).value()[0];
+                auto bad = one; bad[kHeaderOffsetOfChunkOffset()] = 0xFF; bad[kHeaderOffsetOfChunkOffset() + 1] = 0xFF; bad[kHeaderOffsetOfChunkOffset() + 2] = 0xFF;
+                refinish(bad);
+                rep << "chunk_past_end=" << static_cast<int>(wire::parseFrameChunk(bad.data(), bad.size()).error().code) << "\n";
+                bad = one; bad[22 + 17] = 9; bad[22 + 18] = 0; bad[22 + 19] = 3; bad[22 + 20] = 0; refinish(bad);       // index 9 of 3
+                rep << "chunk_bad_index=" << static_cast<int>(wire::parseFrameChunk(bad.data(), bad.size()).error().code) << "\n";
+                wire::FrameAssembler a2(2);
+                wire::FrameData tmp;
+                auto c0 = wire::parseFrameChunk(one.data(), one.size());
+                a2.add(1, c0.value(), &tmp);
+                bad = one; bad[22 + 12] ^= 1; bad[22 + 17] = 1; bad[22 + 21] = 0x60; bad[22 + 22] = 0xEA; bad[22 + 23] = 0; bad[22 + 24] = 0; refinish(bad);   // other width, index 1, offset 60000
+                auto c1 = wire::parseFrameChunk(bad.data(), bad.size());
+                rep << "chunk_contradicts=" << (c1.isOk() ? static_cast<int>(a2.add(1, c1.value(), &tmp).error().code) : -static_cast<int>(c1.error().code)) << "\n";
+                // eviction: a third incomplete frame of the same client pushes the oldest out
+                wire::FrameAssembler a3(2);
+                for (uint32_t id = 1; id <= 3; ++id) {
+                    wire::FrameData f2 = whole; f2.frame_id = id;
+                    auto pk = wire::serializeFrameChunks(f2, 60000, 1, 1).value()[0];
+                    a3.add(5, wire::parseFrameChunk(pk.data(), pk.size()).value(), &tmp);
+                }
+                rep << "chunk_evicted=" << a3.dropped() << "\nchunk_pending_after=" << a3.pending(5) << "\n";
+            }
+        }
     }
     GameState big;                                                        // 1700 detections * 40 B > 65535: refused, not truncated
     big.detections.resize(1700);

@@ -13,6 +13,9 @@ than the threshold, in either of the two runs being compared.  So:
     swap) and which do not suppress the same third nodes: both outcomes are legitimate there and it is skipped (and counted);
   * in every other component the two detection sets must be identical: same number, one-to-one matched with the same
     class, IoU >= min_iou and |confidence difference| <= band;
+  * even inside an ambiguous component the boxes that come BEFORE everything ambiguous in greedy (confidence desc) order, in both
+    runs, are decided identically (greedy NMS looks back only) and are compared exactly: a flip at the confidence threshold -- the lowest
+    box of its class -- taints nothing above it;
   * every detection of the engine must land on an oracle node (same class, IoU >= min_iou): a detection from nowhere
     is an error whatever the bands.
 TEST INFRASTRUCTURE (imported by tests/ only)."""
@@ -131,24 +134,40 @@ def compare_detection_sets(oracle, ref_head, got, img_w, img_h, conf=0.5, iou_th
             if ri != rj:
                 comp[ri] = rj
             if abs(iou[i, j] - iou_thr) <= i_band:
-                amb_edges.append(i)
+                amb_edges += [i, j]
             elif got_head is not None:
                 if (iou[i, j] > iou_thr) != (giou[i, j] > iou_thr):
-                    amb_edges.append(i)                 # this suppression really differs between the two tensors
+                    amb_edges += [i, j]                 # this suppression really differs between the two tensors
                 elif (nodes["confidence"][i] > nodes["confidence"][j]) != (gconf[i] > gconf[j]) or nodes["confidence"][i] == nodes["confidence"][j]:
-                    amb_edges.append(i)                 # the greedy order of the two really differs
+                    amb_edges += [i, j]                 # the greedy order of the two really differs
             elif abs(float(nodes["confidence"][i]) - float(nodes["confidence"][j])) <= band:
                 # the greedy order of i and j may swap: harmless unless they differ in which same-class boxes they suppress
                 si, sj = same[i] & (iou[i] > iou_thr), same[j] & (iou[j] > iou_thr)
                 diff = si != sj
                 diff[i] = diff[j] = False
                 if diff.any():
-                    amb_edges.append(i)
+                    amb_edges += [i, j]
     roots = np.array([find(i) for i in range(n)], dtype=np.int64)
-    ambiguous = set(int(roots[i]) for i in np.nonzero(amb_node)[0]) | set(int(roots[i]) for i in amb_edges)
+    amb_all = sorted(set(int(i) for i in np.nonzero(amb_node)[0]) | set(int(i) for i in amb_edges))
+    ambiguous = set(int(roots[i]) for i in amb_all)
+    # Inside an ambiguous component the clean PREFIX is still compared exactly: greedy NMS decides a box from the boxes before it in
+    # (confidence desc) order only, so a node that precedes -- in the oracle's order AND in the engine's -- every node involved in an
+    # ambiguity of its component (a flipped node, both ends of a flipped / order-swapped edge) is kept or suppressed identically in both
+    # runs.  cutoff[root] = the highest confidence any involved node has in either tensor (+ band without the engine's tensor).
+    lo = nodes["confidence"].copy() if n else np.zeros(0)
+    hi = nodes["confidence"].copy() if n else np.zeros(0)
+    if n and got_head is not None:
+        lo, hi = np.minimum(lo, gconf), np.maximum(hi, gconf)
+    elif n:
+        lo, hi = lo - band, hi + band
+    cutoff = {}
+    for i in amb_all:
+        r = int(roots[i])
+        cutoff[r] = max(cutoff.get(r, -1.0), float(hi[i]))
+    clean = np.array([int(roots[i]) not in cutoff or lo[i] > cutoff[int(roots[i])] for i in range(n)], dtype=bool) if n else np.zeros(0, bool)
 
     def locate(dets, what):
-        """component root of every detection (by its best same-class node), -1 = none"""
+        """node of every detection (its best same-class node by IoU), -1 = none"""
         out = np.full(len(dets), -1, dtype=np.int64)
         if len(dets) == 0 or n == 0:
             if len(dets):
@@ -159,19 +178,22 @@ def compare_detection_sets(oracle, ref_head, got, img_w, img_h, conf=0.5, iou_th
         best = m.argmax(1)
         for k in range(len(dets)):
             if m[k, best[k]] >= min_iou:
-                out[k] = roots[best[k]]
+                out[k] = best[k]
             else:
                 errors.append(f"{what} detection {k} (class {int(dets['class_id'][k])}, conf {float(dets['confidence'][k]):.4f}) matches no oracle "
                               f"candidate: best same-class IoU {float(m[k, best[k]]):.3f}")
         return out
 
-    wc, gc = locate(want, "oracle"), locate(got, "engine")
+    wn, gn = locate(want, "oracle"), locate(got, "engine")
+    wc = np.where(wn >= 0, roots[np.maximum(wn, 0)], -1) if n else wn
+    gc = np.where(gn >= 0, roots[np.maximum(gn, 0)], -1) if n else gn
     compared = skipped = 0
     for root in sorted(set(int(r) for r in roots)):
         wi, gi = np.nonzero(wc == root)[0], np.nonzero(gc == root)[0]
         if root in ambiguous:
-            skipped += len(wi)
-            continue
+            wk = np.array([k for k in wi if clean[wn[k]]], dtype=np.int64)
+            skipped += len(wi) - len(wk)
+            wi, gi = wk, np.array([k for k in gi if clean[gn[k]]], dtype=np.int64)
         compared += len(wi)
         if len(wi) != len(gi):
             errors.append(f"component {root}: oracle keeps {len(wi)} detection(s), engine {len(gi)}")

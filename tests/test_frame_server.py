@@ -37,6 +37,14 @@ def test_packets_in_packets_out(tmp_path, weights_path):
                                              sequence=i, packet_ts=1)                      # short frame: INVALID_INPUT in handleFrameData
         blob.append(struct.pack("<II", client, len(pkt)) + pkt)
         sent.append((client, 500 + i, 9_000_000 + 40 * i, i not in (2, 4)))
+    # a REAL 416x416 frame (519 168 bytes: does not fit one FrameDataPacket) as 9 FrameChunkPackets, arriving shuffled and with a duplicate
+    big = zm.synth_frames(1, 416, 416, seed=78, rects=False)[0]
+    pieces = wire_ref.frame_chunk_packets(frame_id=600, timestamp=9_100_000, width=416, height=416, keyframe=False, pixels=big.tobytes(),
+                                          max_payload=60000, sequence0=50, packet_ts=777)
+    for j in (4, 0, 8, 2, 2, 6, 1, 7, 3, 5):
+        blob.append(struct.pack("<II", 7, len(pieces[j])) + pieces[j])
+    sent.append((7, 600, 9_100_000, True))
+    frames = list(frames) + [big]
     (tmp_path / "in.bin").write_bytes(struct.pack("<I", len(blob)) + b"".join(blob))
     env = dict(os.environ, ZLY_MAX_BATCH="1", ZLY_MODEL_WATCH_MS="0")
     r = subprocess.run([BIN, weights_path, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True, timeout=300, env=env)
@@ -66,4 +74,5 @@ def test_packets_in_packets_out(tmp_path, weights_path):
                 assert np.array_equal(got[name], want[name]), (k, name)
         total += n
     assert struct.unpack_from("<Q", raw, o)[0] == 2 and total > 0                        # the two bad datagrams were counted, not served
+    assert struct.unpack_from("<Q", raw, o + 8)[0] == 1                                  # the chunked 416x416 frame was reassembled and served
     eng.close()

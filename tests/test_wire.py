@@ -64,6 +64,41 @@ def test_cpp_wire_matches_oracle(tmp_path):
     assert rep["dets_too_big"] == "104"                                                # PACKET_TOO_LARGE instead of a truncated length
 
 
+def test_chunked_raw_frame_reassembly_matches_oracle(tmp_path):
+    """The frame that fits the wire (SURVEY 8f rank 1 follow-up): a raw 416x416 frame (519 168 bytes) cannot travel in one
+    FrameDataPacket (16-bit length, protocol.h:42).  FrameChunkPacket (extension, type 8) cuts it into pieces; host/zly_wire.hpp's
+    FrameAssembler must rebuild the exact frame from the pieces in any order, with duplicates, and cut a frame into the very bytes
+    the Python restatement produces."""
+    if not os.path.exists(BIN):
+        subprocess.run(["make", "-C", ROOT, "host"], check=True, stdout=subprocess.DEVNULL)
+    rng = np.random.default_rng(11)
+    w, h = 416, 416
+    pixels = rng.integers(0, 256, w * h * 3, dtype=np.uint8).tobytes()
+    small = wire_ref.frame_data_packet(1, 1, 8, 8, False, bytes(192), 1, 1)
+    (tmp_path / "frame.pkt").write_bytes(small)                                             # the driver's other sections need it
+    pk = wire_ref.frame_chunk_packets(frame_id=4242, timestamp=1700000000777, width=w, height=h, keyframe=True, pixels=pixels,
+                                      max_payload=60000, sequence0=700, packet_ts=555555)
+    assert len(pk) == 9 and all(len(p) <= 22 + 25 + 60000 for p in pk) and wire_ref.check(pk[0], wire_ref.FRAME_CHUNK) == 0
+    assert wire_ref.reassemble(pk[:-1]) is None and wire_ref.reassemble(pk) == (4242, 1700000000777, w, h, True, pixels)
+    order = [5, 0, 8, 0, 3, 1, 7, 2, 6, 4]                                                  # shuffled arrival, piece 0 twice
+    arrive = [pk[i] for i in order]
+    (tmp_path / "chunks.bin").write_bytes(struct.pack("<I", len(arrive)) + b"".join(struct.pack("<I", len(p)) + p for p in arrive))
+    r = subprocess.run([BIN, str(tmp_path)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    rep = dict(line.split("=", 1) for line in (tmp_path / "report.txt").read_text().splitlines())
+    assert rep["chunks_completed"] == "1" and rep["chunks_errors"] == "0" and rep["chunks_complete_at"] == str(len(order) - 1) and rep["chunks_pending"] == "0"
+    assert (rep["chunks_frame_id"], rep["chunks_ts"], rep["chunks_w"], rep["chunks_h"], rep["chunks_key"]) == ("4242", "1700000000777", "416", "416", "1")
+    assert (tmp_path / "chunks_frame.bin").read_bytes() == pixels                           # byte-exact reassembly
+    out = (tmp_path / "chunks_out.bin").read_bytes()
+    o, got = 0, []
+    while o < len(out):
+        nb = struct.unpack_from("<I", out, o)[0]; o += 4
+        got.append(out[o:o + nb]); o += nb
+    assert rep["chunks_serialize"] == "0" and got == pk                                     # the C++ cutter == the oracle, byte for byte
+    assert rep["chunk_past_end"] == "103" and rep["chunk_bad_index"] == "103" and rep["chunk_contradicts"] == "103"    # INVALID_PACKET
+    assert rep["chunk_evicted"] == "1" and rep["chunk_pending_after"] == "2"
+
+
 def test_wire_oracle_matches_committed_vectors():
     """tests/golden/wire_golden.json (made by tests/golden/make_wire_golden.py) pins the Python restatement itself."""
     import importlib.util

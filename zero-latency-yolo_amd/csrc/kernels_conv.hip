@@ -832,6 +832,187 @@ static size_t lds_bytes(int stride, int pt, int ct, int wchunks = 1) {
     return patch + (size_t)wchunks * 9 * ct * 1024;
 }
 
+// ------------------------------------------------------------------------------------------------
+// 3x3 convolution, WEIGHT-STATIONARY PER WAVE (bf16, stride 1, pad 1, Cin = 32 * NKS / 9): the kernel of the FLOP-dense layers -- the
+// Detect branches at P3 / P4 and the 64-channel bottlenecks at 26 x 26.
+//
+// What the stamped builds showed (profiles/r03_lds_kernel_phase_stamps.txt, r03_ps_kernel_phase_stamps.txt): conv3x3_lds_kernel and a
+// first pixel-stationary variant with a weight ring in LDS both ran the P3 stem at ~560 TFLOP/s although their inner loop alone does
+// 1770 (tools/mfma_bench.hip): per tile a wave spent 30 k of 50 k cycles issuing weight DMAs (~100 cycles per KiB), waiting for them,
+// in one barrier per k-step and in the epilogue.  The weights are the problem, so here they never move:
+//   * the output channels are split over the waves of a workgroup: a wave owns TPW = 2 of the 16-channel tiles (8 consecutive channels
+//     per lane with the pair-permuted rows) and keeps their weight fragments for ALL NKS k-steps in registers (2 x 18 x 4 = 144 VGPRs
+//     for Cin = 64), loaded once per workgroup;
+//   * a workgroup owns a TH x TW pixel tile of one frame (13 x 26 divides the 52 x 52 and 26 x 26 maps); its input patch goes to LDS once
+//     (pixel pitch Cin*2 + 32 B: conflict-free ds_read_b128); the pixels are linearised into 16-pixel column tiles and each wave
+//     streams the column tiles of its pixel group past its weights: per column tile NKS pixel fragments from LDS, TPW * NKS MFMAs,
+//     bias + SiLU + ONE 16-byte NHWC store per lane -- no barrier, no wait on another wave, anywhere in the loop;
+//   * a workgroup = 4 waves = NWC channel groups x NWP pixel groups (128 channels: 4 x 1, 64: 2 x 2, 32: 1 x 4), two workgroups per CU
+//     (256 VGPRs per lane, <= 80 KB LDS); an odd tile count (the 64 -> 144 Detect stem: 9 tiles) runs its last tile as a second launch of
+//     the TPW = 1 form (1 x 4 waves).
+// ------------------------------------------------------------------------------------------------
+struct WsGeom { int TH, TW, tiles_x, tiles_y, total_tiles, pitch, nchunks, nwc, nwp; };
+#ifdef ZLY_WS_DIAG
+__device__ unsigned long long* g_ws_diag = nullptr;              // diagnostic build only (tools/ws_bench.hip): per-wave phase cycle sums
+#endif
+
+template <int TPW, int NKS>
+__global__ __launch_bounds__(256, 2) void conv3x3_ws_kernel(const ConvArgs a, const WsGeom g)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* lpatch = smem;
+    const int PW = g.TW + 2, PH = g.TH + 2;
+    const int nthreads = blockDim.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p = lane & 15, kq = lane >> 4;
+    const int wc = wave % g.nwc, wp = wave / g.nwc;               // channel group, pixel group of this wave
+    const int ntiles_c = (a.cout_pad + 15) >> 4;
+    const bf16_t* __restrict__ in = static_cast<const bf16_t*>(a.in) + a.in_co;
+    const int upp = a.Cin >> 3;                                 // 16-byte units per patch pixel
+    const int NPU = PH * PW * upp;
+    const float inv_upp = 1.0f / (float)upp, invPW = 1.0f / (float)PW, invTW = 1.0f / (float)g.TW;
+    const int NPB = g.TH * g.TW, nct = (NPB + 15) >> 4;          // pixels / 16-pixel column tiles of a tile
+    const int tiles_per_img = g.tiles_x * g.tiles_y;
+
+    // ---- this wave's weights: tiles wc * TPW .. + TPW - 1, every k-step, resident in registers for the workgroup's lifetime ----
+    bf16x8 w[TPW][NKS];
+    {
+        const bf16_t* __restrict__ wb = static_cast<const bf16_t*>(a.wgt) + lane * 8;
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+            const int tile = min(wc * TPW + t, ntiles_c - 1);       // a group's surplus tile (odd tile counts) re-reads the last one; its results are not stored
+#pragma unroll
+            for (int s = 0; s < NKS; ++s) w[t][s] = *reinterpret_cast<const bf16x8*>(wb + ((size_t)tile * a.nk + s) * 512);
+        }
+    }
+    f32x4 biasr[TPW];
+    load_bias<TPW>(a, wc * TPW, kq, biasr);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (unsigned)((size_t)a.M * a.out_cs * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.res ? a.res : a.out), 0,
+                                                                          (unsigned)((size_t)a.M * (a.res ? a.res_cs : a.out_cs) * 2), 0x00020000);
+    // tap offsets of the k-steps inside the patch (wave-uniform): k-step s = tap * nchunks + chunk
+    int toff[NKS];
+#pragma unroll
+    for (int s = 0; s < NKS; ++s) {
+        const int tap = s / (NKS / 9), chunk = s - tap * (NKS / 9);
+        const int ky = tap / 3, kx = tap - ky * 3;
+        toff[s] = (ky * PW + kx) * g.pitch + chunk * 64;
+    }
+#ifdef ZLY_WS_DIAG
+    unsigned long long dsum[4] = {0, 0, 0, 0}, dT0 = 0, dT1 = 0;
+#define WSSTAMP(t) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define WSPHASE(k) do { WSSTAMP(dT1); dsum[k] += dT1 - dT0; dT0 = dT1; } while (0)
+    const unsigned long long dstart = __builtin_amdgcn_s_memtime();
+    WSSTAMP(dT0);
+#else
+#define WSPHASE(k) do { } while (0)
+#endif
+
+    for (int tl = blockIdx.x; tl < g.total_tiles; tl += gridDim.x) {
+        const int b = tl / tiles_per_img;
+        const int r = tl - b * tiles_per_img;
+        const int ty = r / g.tiles_x;
+        const int y0 = ty * g.TH, x0 = (r - ty * g.tiles_x) * g.TW;
+        __syncthreads();                                        // the previous tile's readers of the patch are done
+        WSPHASE(0);
+        // ---- input patch: global -> LDS, zero outside the frame (the conv's padding) ----------------------------------------------
+        for (int u0 = 0; u0 < NPU; u0 += nthreads * 4) {
+            u32x4 v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int u = u0 + i * nthreads + tid;
+                v[i] = u32x4{0u, 0u, 0u, 0u};
+                if (u < NPU) {
+                    const int px = (int)(((float)u + 0.5f) * inv_upp), part = u - px * upp;
+                    const int py = (int)(((float)px + 0.5f) * invPW), pxx = px - py * PW;
+                    const int gy = y0 - 1 + py, gx = x0 - 1 + pxx;
+                    if ((unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W)
+                        v[i] = *reinterpret_cast<const u32x4*>(in + ((size_t)(b * a.H + gy) * a.W + gx) * a.in_cs + part * 8);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int u = u0 + i * nthreads + tid;
+                if (u < NPU) {
+                    const int px = (int)(((float)u + 0.5f) * inv_upp), part = u - px * upp;
+                    *reinterpret_cast<u32x4*>(lpatch + px * g.pitch + part * 16) = v[i];
+                }
+            }
+        }
+        __syncthreads();
+        WSPHASE(1);
+        // ---- this wave's column tiles: wp, wp + nwp, ... ----------------------------------------------------------------------------
+        for (int t = wp; t < nct; t += g.nwp) {
+            const int q = t * 16 + p;
+            const int qc = min(q, NPB - 1);
+            const int oy = (int)(((float)qc + 0.5f) * invTW), ox = qc - oy * g.TW;
+            const unsigned char* px = lpatch + (oy * PW + ox) * g.pitch + kq * 16;
+            f32x4 acc[TPW];
+#pragma unroll
+            for (int c = 0; c < TPW; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // pixel fragments are read WS_DEPTH k-steps ahead of the MFMAs that consume them (statically indexed ring)
+            constexpr int WS_DEPTH = 4;
+            bf16x8 xf[WS_DEPTH + 1];
+#pragma unroll
+            for (int s = 0; s < WS_DEPTH; ++s) xf[s] = *reinterpret_cast<const bf16x8*>(px + toff[s]);
+#pragma unroll
+            for (int s = 0; s < NKS; ++s) {
+                if (s + WS_DEPTH < NKS) xf[(s + WS_DEPTH) % (WS_DEPTH + 1)] = *reinterpret_cast<const bf16x8*>(px + toff[s + WS_DEPTH]);
+#pragma unroll
+                for (int c = 0; c < TPW; ++c) acc[c] = mma_step(w[c][s], xf[s % (WS_DEPTH + 1)], acc[c]);
+            }
+            const int gy = y0 + oy, gx = x0 + ox;
+            if (q < NPB && gy < a.Ho && gx < a.Wo) epilogue_px_buf<TPW>(a, rout, rres, acc, biasr, wc * TPW, kq, (b * a.Ho + gy) * a.Wo + gx);
+        }
+        WSPHASE(2);
+    }
+#ifdef ZLY_WS_DIAG
+    if (lane == 0 && g_ws_diag) {
+        unsigned long long* o = g_ws_diag + ((size_t)blockIdx.x * (blockDim.x >> 6) + wave) * 8;
+        for (int k = 0; k < 3; ++k) o[k] = dsum[k];
+        o[3] = __builtin_amdgcn_s_memtime() - dstart;
+    }
+#endif
+}
+
+typedef void (*conv_ws_fn)(const ConvArgs, const WsGeom);
+static conv_ws_fn pick_ws(int cin, int tpw)
+{
+    if (cin != 64) return nullptr;
+    return tpw == 2 ? conv3x3_ws_kernel<2, 18> : conv3x3_ws_kernel<1, 18>;
+}
+static constexpr int WS_LDS_MAX = 80 * 1024;
+
+// tile shape: among the shapes whose patch fits the 80 KB of one of two resident workgroups, the one that needs the fewest tiles, then
+// computes the fewest pixels beyond the map, then has the smallest patch
+static bool ws_plan(int H, int W, int cin, WsGeom* g)
+{
+    if (!pick_ws(cin, 2)) return false;
+    const int pitch = cin * 2 + 32;
+    long best = -1;
+    for (int th = 4; th <= 32; ++th)
+        for (int tw = 8; tw <= 32; ++tw) {
+            const long lds = ((long)(th + 2) * (tw + 2) * pitch + 15) / 16 * 16;
+            if (lds > WS_LDS_MAX) continue;
+            const int tx = (W + tw - 1) / tw, ty = (H + th - 1) / th;
+            const long tiles = (long)tx * ty;
+            const long waste = (long)tx * tw * ty * th - (long)H * W;
+            const long key = (tiles * 100000 + waste) * 2000 + (th + 2) * (tw + 2);
+            if (best < 0 || key < best) { best = key; g->TH = th; g->TW = tw; g->tiles_x = tx; g->tiles_y = ty; }
+        }
+    if (best < 0) return false;
+    g->pitch = pitch; g->nchunks = cin / 32;
+    return true;
+}
+
+hipError_t ws_init()
+{
+    hipError_t r = hipFuncSetAttribute((const void*)pick_ws(64, 2), hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_MAX);
+    if (r != hipSuccess) return r;
+    return hipFuncSetAttribute((const void*)pick_ws(64, 1), hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_MAX);
+}
+
 static int g_num_cus = 256;
 int num_cus() { return g_num_cus; }
 void set_num_cus(int n) { g_num_cus = n < 1 ? 1 : (n > 256 ? 256 : n); }
@@ -839,6 +1020,7 @@ void set_num_cus(int n) { g_num_cus = n < 1 ? 1 : (n > 256 ? 256 : n); }
 // dynamic LDS above 64 KiB needs an opt-in per kernel; done once, outside any stream capture
 hipError_t conv_init()
 {
+    { hipError_t r = ws_init(); if (r != hipSuccess) return r; }
     static const int pts1[3] = {1, 2, 4}, pts2[2] = {1, 2};
     for (int ct = 2; ct <= 5; ++ct) {
         for (int i = 0; i < 3; ++i) {
@@ -938,12 +1120,30 @@ static bool pick_stream_config(int cin, int cout_pad, int M, ConvLaunch* cfg)
     return true;
 }
 
-void conv_pick_config(int dtype, int ks, int stride, int cin, int cout_pad, int n, int Ho, int Wo, ConvLaunch* cfg, bool streamable)
+// weight-stationary 3x3 kernel: stride-1 layers with Cin = 64 and 32 / 64 / 128 (+ 16) output channels on maps its tiles cover well, with
+// enough tiles to fill the chip
+static bool pick_ws_config(int stride, int cin, int cout_pad, int n, int Ho, int Wo, ConvLaunch* cfg)
+{
+    static const bool off = getenv("ZLY_NO_WS") != nullptr;        // tuning / tests
+    const int even = cout_pad / 16 / 2 * 2;                         // tiles of the TPW = 2 launch; an odd last tile goes to a TPW = 1 launch
+    if (off || stride != 1 || cout_pad % 16 || (even != 2 && even != 4 && even != 8)) return false;
+    WsGeom g{};
+    if (!ws_plan(Ho, Wo, cin, &g)) return false;
+    const long tiles = (long)n * g.tiles_x * g.tiles_y;
+    const double util = (double)Ho * Wo / ((double)g.tiles_x * g.tiles_y * g.TH * g.TW);
+    const char* mt = getenv("ZLY_WS_MIN_TILES");
+    if (util < 0.7 || tiles < (mt ? atol(mt) : 256)) return false;
+    cfg->ps = 1; cfg->ct = cout_pad / 16; cfg->pt = 4; cfg->ksplit = 1; cfg->fastk = 1;
+    return true;
+}
+
+void conv_pick_config(int dtype, int ks, int stride, int cin, int cout_pad, int n, int Ho, int Wo, ConvLaunch* cfg, bool streamable, bool plain)
 {
     const int M = n * Ho * Wo;
-    cfg->ks = ks; cfg->lds = 0; cfg->stream = 0; cfg->wres = 0;
+    cfg->ks = ks; cfg->lds = 0; cfg->stream = 0; cfg->wres = 0; cfg->ps = 0;
     const bool no_stream = getenv("ZLY_NO_STREAM") != nullptr;             // tuning / tests
     if (dtype == ZLY_DTYPE_BF16 && ks == 1 && stride == 1 && streamable && !no_stream && pick_stream_config(cin, cout_pad, M, cfg)) return;
+    if (dtype == ZLY_DTYPE_BF16 && ks == 3 && plain && pick_ws_config(stride, cin, cout_pad, n, Ho, Wo, cfg)) return;
     if (dtype == ZLY_DTYPE_BF16 && ks == 3 && pick_lds_config(stride, cin, cout_pad, n, Ho, Wo, cfg)) return;
     conv_pick_direct(dtype, ks, cin, cout_pad, M, cfg);
 }
@@ -951,7 +1151,7 @@ void conv_pick_config(int dtype, int ks, int stride, int cin, int cout_pad, int 
 void conv_pick_direct(int dtype, int ks, int cin, int cout_pad, int M, ConvLaunch* cfg)
 {
     const int kstep = conv_kstep(dtype);
-    cfg->ks = ks; cfg->stream = 0; cfg->wres = 0;
+    cfg->ks = ks; cfg->stream = 0; cfg->wres = 0; cfg->ps = 0;
     cfg->fastk = (ks == 3 && cin % kstep == 0) ? 1 : 0;
     cfg->ksplit = 1;
     const int ntiles = cout_pad / 16;
@@ -988,6 +1188,34 @@ void conv_pick_direct(int dtype, int ks, int cin, int cout_pad, int M, ConvLaunc
 
 hipError_t launch_conv(int dtype, const ConvArgs& a, const ConvLaunch& cfg, hipStream_t s)
 {
+    if (cfg.ps) {                                                  // weight-stationary 3x3 kernel
+        WsGeom g{};
+        const int ntiles = a.cout_pad / 16, even = ntiles / 2 * 2;
+        if (dtype != ZLY_DTYPE_BF16 || !pick_ws(a.Cin, 2) || a.stride != 1 || a.pad != 1 || a.in2 || a.out_f32 || a.nk != 9 * a.Cin / 32 ||
+            a.in_cs % 8 || a.in_co % 8 || (even != 2 && even != 4 && even != 8) || !ws_plan(a.Ho, a.Wo, a.Cin, &g)) return hipErrorInvalidValue;
+        const int n = a.M / (a.Ho * a.Wo);
+        g.total_tiles = g.tiles_x * g.tiles_y * n;
+        const size_t lds = ((size_t)(g.TH + 2) * (g.TW + 2) * g.pitch + 15) / 16 * 16;
+        const int gx = g.total_tiles < 2 * num_cus() ? g.total_tiles : 2 * num_cus();      // persistent: two resident workgroups per CU
+        // the even tiles: 4 waves = (even / 2) channel groups x pixel groups
+        ConvArgs m = a;
+        m.cout_pad = even * 16;
+        m.Cout = a.Cout < even * 16 ? a.Cout : even * 16;
+        g.nwc = even / 2; g.nwp = 4 / g.nwc;
+        hipLaunchKernelGGL(pick_ws(a.Cin, 2), dim3(gx), dim3(256), lds, s, m, g);
+        if (ntiles > even && a.Cout > even * 16) {
+            // the odd last tile (pair-permuted rows cover the even tiles only, so it is a plain 16-channel conv of its own): 1 x 4 waves
+            ConvArgs r = a;
+            r.wgt = static_cast<const char*>(a.wgt) + (size_t)even * a.nk * 1024;
+            r.bias = a.bias + even * 16;
+            r.out_co = a.out_co + even * 16;
+            if (a.res) r.res_co = a.res_co + even * 16;
+            r.Cout = a.Cout - even * 16; r.cout_pad = 16;
+            g.nwc = 1; g.nwp = 4;
+            hipLaunchKernelGGL(pick_ws(a.Cin, 1), dim3(gx), dim3(256), lds, s, r, g);
+        }
+        return hipGetLastError();
+    }
     if (cfg.lds) {
         conv_lds_fn fn = pick_lds(a.stride, cfg.pt, cfg.ct);
         if (!fn || dtype != ZLY_DTYPE_BF16) return hipErrorInvalidValue;

@@ -9,6 +9,7 @@
 // round trip through HBM.  decode here and decode_kernel (kernels_post.hip, used by zly_postprocess)
 // apply the same comparisons to the same fp32 values, so both give the same candidates.
 #include "zly_internal.h"
+#include <math.h>
 
 #pragma clang fp contract(off)
 
@@ -66,21 +67,23 @@ __global__ __launch_bounds__(256) void head_fused_kernel(const HeadArgs a)
 #pragma unroll
     for (int j = 0; j < EPL; ++j) zero[j] = (T)0.0f;
 
-    // ---- box branch: [64 x cin] . [cin x 16] ----------------------------------------------------
-    f32x4 accb[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) accb[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // All fragments of the tile -- both branches, every k-step -- are requested before the first MFMA: with the loads inside the k-step loops
+    // (trip counts are run-time values) every k-step exposed one memory round trip, five per wave, and a wave lived 19 k cycles of which
+    // 60 % in s_waitcnt (PMC, profiles/r02_final_pmc_kernels.txt): 42 us per batch-64 step for 65 MB.
+    constexpr int KMAX = 8;                                  // k-steps of a branch: bf16 80/128 channels -> 3/4, fp32 -> 5/8
+    F xb[KMAX], xc[KMAX];
     {
-        const T* x = static_cast<const T*>(L.box_in) + pix * L.box_cs;
-        const T* w = static_cast<const T*>(L.wb) + lane * EPL;
-        for (int s = 0; s < L.nkb; ++s) {
-            const int ci = s * KSTEP + kq * EPL;
-            const F af = (valid && ci < L.box_cin) ? *reinterpret_cast<const F*>(x + ci) : zero;
+        const T* pb = static_cast<const T*>(L.box_in) + pix * L.box_cs;
+        const T* pc = static_cast<const T*>(L.cls_in) + pix * L.cls_cs;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const F wf = *reinterpret_cast<const F*>(w + ((size_t)c * L.nkb + s) * WTILE);
-                accb[c] = hmma(wf, af, accb[c]);
-            }
+        for (int s = 0; s < KMAX; ++s) {
+            const int ci = s * KSTEP + kq * EPL;
+            xc[s] = zero; xb[s] = zero;
+#ifdef ZLY_HEAD_DIAG
+            if (a.diag & 2) continue;                              // diagnostic: no activation loads
+#endif
+            if (s < L.nkc && valid && ci < L.cls_cin) xc[s] = *reinterpret_cast<const F*>(pc + ci);
+            if (s < L.nkb && valid && ci < L.box_cin) xb[s] = *reinterpret_cast<const F*>(pb + ci);
         }
     }
     // ---- class branch: [nc x cin] . [cin x 16] ---------------------------------------------------
@@ -88,15 +91,55 @@ __global__ __launch_bounds__(256) void head_fused_kernel(const HeadArgs a)
 #pragma unroll
     for (int c = 0; c < CTC; ++c) accc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
     {
-        const T* x = static_cast<const T*>(L.cls_in) + pix * L.cls_cs;
         const T* w = static_cast<const T*>(L.wc) + lane * EPL;
-        for (int s = 0; s < L.nkc; ++s) {
-            const int ci = s * KSTEP + kq * EPL;
-            const F af = (valid && ci < L.cls_cin) ? *reinterpret_cast<const F*>(x + ci) : zero;
 #pragma unroll
-            for (int c = 0; c < CTC; ++c) {
-                const F wf = *reinterpret_cast<const F*>(w + ((size_t)c * L.nkc + s) * WTILE);
-                accc[c] = hmma(wf, af, accc[c]);
+        for (int s = 0; s < KMAX; ++s) {
+            if (s < L.nkc) {
+#pragma unroll
+                for (int c = 0; c < CTC; ++c) {
+#ifdef ZLY_HEAD_DIAG
+                    if (a.diag & 1) { accc[c] = hmma(xc[(s + c) % KMAX], xc[s], accc[c]); continue; }      // diagnostic: no weight loads
+#endif
+                    const F wf = *reinterpret_cast<const F*>(w + ((size_t)c * L.nkc + s) * WTILE);
+                    accc[c] = hmma(wf, xc[s], accc[c]);
+                }
+            }
+        }
+    }
+    // Early out (production: no head tensor, no logit dump): when NO anchor of the tile has a class logit above skip_logit =
+    // logit(conf_thr) - 1e-2, none can reach the confidence threshold (the margin is four orders of magnitude above the error of
+    // v_exp / v_rcp), and the box GEMM, the DFL and the 80 sigmoids per anchor are skipped -- ~4 of 5 tiles on a detector that passes
+    // ~1.5 % of its anchors.  Tiles that are not skipped run the full arithmetic below, so the candidates are exactly the same.
+#ifdef ZLY_HEAD_DIAG
+    if (a.diag & 4) { if (accc[0][0] == 123.456f && a.cand_count) a.cand_count[f] = 1; return; }         // diagnostic: stop after the class GEMM
+#endif
+    if (a.head == nullptr && L.logits == nullptr) {
+        float zmax = -3.0e38f;
+#pragma unroll
+        for (int c = 0; c < CTC; ++c) {
+            const int ch = c * 16 + kq * 4;
+            const f32x4 bias = *reinterpret_cast<const f32x4*>(L.bc + ch);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (ch + r < a.nc) zmax = fmaxf(zmax, accc[c][r] + bias[r]);
+        }
+        zmax = fmaxf(zmax, __shfl_xor(zmax, 16));
+        zmax = fmaxf(zmax, __shfl_xor(zmax, 32));
+        if (__ballot(valid && zmax >= a.skip_logit) == 0ull) return;
+    }
+    // ---- box branch: [64 x cin] . [cin x 16] ----------------------------------------------------
+    f32x4 accb[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) accb[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    {
+        const T* w = static_cast<const T*>(L.wb) + lane * EPL;
+#pragma unroll
+        for (int s = 0; s < KMAX; ++s) {
+            if (s < L.nkb) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const F wf = *reinterpret_cast<const F*>(w + ((size_t)c * L.nkb + s) * WTILE);
+                    accb[c] = hmma(wf, xb[s], accb[c]);
+                }
             }
         }
     }
@@ -206,8 +249,13 @@ template <typename T> static head_fn pick_head(int ctc) {
     return nullptr;
 }
 
-hipError_t launch_head_fused(int dtype, const HeadArgs& a, int n, hipStream_t s)
+hipError_t launch_head_fused(int dtype, const HeadArgs& a0, int n, hipStream_t s)
 {
+    HeadArgs a = a0;
+    // the class logit below which no score can reach conf_thr (see the kernel): logit(thr) minus a margin; thr <= 0 keeps everything,
+    // thr >= 1 needs sigmoid(z) to round to 1.0f, i.e. z > 17
+    const double thr = (double)a.conf_thr;
+    a.skip_logit = thr <= 0.0 ? -3.0e38f : (thr >= 1.0 ? 15.0f : (float)(log(thr / (1.0 - thr)) - 1e-2));
     const int ctc = (a.nc + 15) / 16;
     head_fn fn = dtype == ZLY_DTYPE_BF16 ? pick_head<bf16_t>(ctc) : pick_head<float>(ctc);
     if (!fn) return hipErrorInvalidValue;                  // nc > 80 is not supported by this kernel

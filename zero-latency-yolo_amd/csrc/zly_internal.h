@@ -40,7 +40,7 @@ struct ConvArgs {
     const void* in2;  int in2_cs, in2_co, split_c;
 };
 
-struct ConvLaunch { int ks, ct, pt, fastk, ksplit, lds, stream, wres; };
+struct ConvLaunch { int ks, ct, pt, fastk, ksplit, lds, stream, wres, ps; };
 struct ConvArgsMulti { ConvArgs a[6]; int n; };       // independent convs of one launch (conv_igemm_multi_kernel)
 hipError_t launch_conv_multi(const ConvArgsMulti& m, int ct, hipStream_t s);
 
@@ -52,7 +52,8 @@ void set_num_cus(int n);
 // kernels_conv.hip
 hipError_t launch_conv(int dtype, const ConvArgs& a, const ConvLaunch& cfg, hipStream_t s);
 void       conv_pick_config(int dtype, int ks, int stride, int cin, int cout_pad, int n, int Ho, int Wo, ConvLaunch* cfg,
-                            bool streamable = false);   // streamable: single source, no residual, SiLU, bf16 output, Cout % 32 == 0
+                            bool streamable = false,    // single source, no residual, SiLU, bf16 output, Cout % 32 == 0
+                            bool plain = false);        // single source, no residual, activation dtype output: may take the pixel-stationary 3x3 kernel
 hipError_t conv_init();
 int        conv_kstep(int dtype);
 
@@ -135,6 +136,8 @@ struct HeadArgs {
     int only_level;                           // -1: all three levels in one launch; 0..2: that level only (its own launch, beside the neck)
     float* head;                              // [n][4+nc][N_total] or null
     const FrameDesc* desc; float conf_thr;
+    float skip_logit;                         // set by launch_head_fused: class logit below which no score reaches conf_thr
+    int diag;                                 // diagnostic builds only (tools/head_bench.hip); 0 in the product
     struct Cand* cand; int* cand_count;
 };
 hipError_t launch_head_fused(int dtype, const HeadArgs& a, int n, hipStream_t s);

@@ -10,6 +10,7 @@
 
 #include <atomic>
 #include <chrono>
+#include <mutex>
 
 namespace zero_latency {
 
@@ -23,9 +24,26 @@ class FrameServer {
         engine_.setCallback([this](uint32_t client_id, const GameState& state) { onInferenceResult(client_id, state); });
     }
 
-    // one datagram from `client_id` (the reference resolves the id from the sender address, :88-110)
+    // one datagram from `client_id` (the reference resolves the id from the sender address, :88-110): a whole frame (FrameDataPacket,
+    // the reference's format: frames up to 65518 bytes) or one piece of a chunked raw frame (FrameChunkPacket, zly_wire.hpp)
     Result<void> onPacket(uint32_t client_id, const uint8_t* data, size_t size)
     {
+        if (size > 5 && data[5] == wire::kTypeFrameChunk) {
+            auto chunk = wire::parseFrameChunk(data, size);
+            if (chunk.hasError()) { ++bad_packets_; return Result<void>::error(chunk.error()); }
+            wire::FrameData whole;
+            Result<bool> done = Result<bool>::ok(false);
+            {
+                std::lock_guard<std::mutex> lk(assembler_mutex_);         // the reference's receive path is one thread; be safe for several
+                done = assembler_.add(client_id, chunk.value(), &whole);
+            }
+            if (done.hasError()) { ++bad_packets_; return Result<void>::error(done.error()); }
+            if (!done.value()) return Result<void>::ok();                 // more pieces to come
+            ++reassembled_frames_;
+            auto req = wire::frameToRequest(whole, client_id);
+            if (req.hasError()) { ++bad_packets_; return Result<void>::error(req.error()); }
+            return engine_.submitInference(req.value());
+        }
         auto frame = wire::parseFrameData(data, size);
         if (frame.hasError()) { ++bad_packets_; return Result<void>::error(frame.error()); }
         auto req = wire::frameToRequest(frame.value(), client_id);
@@ -33,6 +51,8 @@ class FrameServer {
         return engine_.submitInference(req.value());
     }
 
+    uint64_t reassembledFrames() const { return reassembled_frames_; }
+    uint64_t droppedIncompleteFrames() const { std::lock_guard<std::mutex> lk(assembler_mutex_); return assembler_.dropped(); }
     uint64_t badPackets() const { return bad_packets_; }
     uint64_t sentPackets() const { return sent_packets_; }
 
@@ -52,7 +72,9 @@ class FrameServer {
     Cs16DetectionStep& adapter_;
     SendFn send_;
     std::atomic<uint32_t> sequence_{0};
-    std::atomic<uint64_t> bad_packets_{0}, sent_packets_{0};
+    std::atomic<uint64_t> bad_packets_{0}, sent_packets_{0}, reassembled_frames_{0};
+    mutable std::mutex assembler_mutex_;
+    wire::FrameAssembler assembler_;
 };
 
 }  // namespace zero_latency

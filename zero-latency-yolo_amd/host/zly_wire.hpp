@@ -17,15 +17,24 @@
 //   frame -> request        NetworkServer::handleFrameData (network_server.cpp:184-207): empty data / zero dims /
 //                           data.size() != w*h*3 -> INVALID_INPUT (203); fields copied 1:1, client id from the session.
 //
+//   FrameChunkPacket        EXTENSION (no reference counterpart; type 8, the first value PacketType leaves free, types.h:73-82): a raw
+//                           frame cut into pieces that fit the 16-bit length.  Same header / CRC rules; body = the FrameDataPacket
+//                           fields (frame_id u32, timestamp u64, width u16, height u16, keyframe u8) + chunk_index u16,
+//                           chunk_count u16, offset u32 (byte offset of this piece in the w*h*3 frame), then the piece.
+//                           FrameAssembler puts the pieces of a frame back together (any order, duplicates ignored) and hands over
+//                           the same FrameData a single FrameDataPacket would have carried.
+//
 // Known limits of the reference format, kept: `length` is 16 bits, so a body cannot exceed 65535 bytes (a raw
 // 416x416 frame is 519168 bytes and does not fit one packet; the reference's client sends JPEG which its server
-// cannot decode).  serialize* here refuse bodies that do not fit instead of truncating the
-// length as the reference's static_cast does (protocol.h:178).
+// cannot decode); FrameChunkPacket above is how a real frame reaches this server.  serialize* here refuse
+// bodies that do not fit instead of truncating the length as the reference's static_cast does (protocol.h:178).
 #pragma once
 
 #include "zly_compat.hpp"
 
 #include <cstring>
+#include <deque>
+#include <map>
 
 namespace zero_latency {
 namespace wire {
@@ -35,6 +44,9 @@ constexpr uint8_t kVersion = 1;
 constexpr size_t kHeaderSize = 22;
 constexpr uint8_t kTypeFrameData = 3;          // PacketType::FRAME_DATA (types.h:73-82)
 constexpr uint8_t kTypeDetectionResult = 4;    // PacketType::DETECTION_RESULT
+constexpr uint8_t kTypeFrameChunk = 8;         // extension: PacketType ends at CONFIG_UPDATE = 7
+constexpr size_t kChunkBodyHeader = 25;        // frame_id 4 + timestamp 8 + width 2 + height 2 + keyframe 1 + index 2 + count 2 + offset 4
+constexpr size_t kMaxChunkPayload = 0xFFFF - kChunkBodyHeader;
 
 struct Header {
     uint32_t magic = kMagic;
@@ -186,6 +198,123 @@ inline Result<GameState> parseDetectionResult(const uint8_t* data, size_t size, 
     if (count) std::memcpy(s.detections.data(), b + 14, (size_t)count * sizeof(Detection));
     return R::ok(std::move(s));
 }
+
+// ---- chunked raw frames (extension) ---------------------------------------------------------------------------------------------
+struct FrameChunk {
+    uint32_t frame_id = 0;
+    uint64_t timestamp = 0;
+    uint16_t width = 0, height = 0;
+    bool keyframe = false;
+    uint16_t index = 0, count = 0;
+    uint32_t offset = 0;
+    const uint8_t* payload = nullptr;          // points into the parsed packet
+    size_t payload_size = 0;
+};
+
+// a frame -> ceil(bytes / max_payload) packets, sequence numbers sequence0, sequence0 + 1, ...
+inline Result<std::vector<std::vector<uint8_t>>> serializeFrameChunks(const FrameData& f, size_t max_payload, uint32_t sequence0, uint64_t packet_timestamp)
+{
+    using R = Result<std::vector<std::vector<uint8_t>>>;
+    if (max_payload == 0 || max_payload > kMaxChunkPayload) return R::error(ErrorCode::INVALID_ARGUMENT, "chunk payload must be 1.." + std::to_string(kMaxChunkPayload) + " bytes");
+    if (f.data.empty() || f.data.size() != (size_t)f.width * f.height * 3) return R::error(ErrorCode::INVALID_INPUT, "a chunked frame is raw w*h*3 bytes");
+    const size_t count = (f.data.size() + max_payload - 1) / max_payload;
+    if (count > 0xFFFF) return R::error(ErrorCode::PACKET_TOO_LARGE, "frame needs more than 65535 chunks");
+    std::vector<std::vector<uint8_t>> out;
+    for (size_t i = 0; i < count; ++i) {
+        const size_t off = i * max_payload, nb = std::min(max_payload, f.data.size() - off);
+        std::vector<uint8_t> pkt(kHeaderSize + kChunkBodyHeader + nb);
+        size_t o = kHeaderSize;
+        detail::put<uint32_t>(pkt, o, f.frame_id); o += 4;
+        detail::put<uint64_t>(pkt, o, f.timestamp); o += 8;
+        detail::put<uint16_t>(pkt, o, f.width); o += 2;
+        detail::put<uint16_t>(pkt, o, f.height); o += 2;
+        pkt[o++] = f.keyframe ? 1 : 0;
+        detail::put<uint16_t>(pkt, o, (uint16_t)i); o += 2;
+        detail::put<uint16_t>(pkt, o, (uint16_t)count); o += 2;
+        detail::put<uint32_t>(pkt, o, (uint32_t)off); o += 4;
+        std::memcpy(pkt.data() + o, f.data.data() + off, nb);
+        if (!detail::finish(pkt, kTypeFrameChunk, sequence0 + (uint32_t)i, packet_timestamp)) return R::error(ErrorCode::PACKET_TOO_LARGE, "chunk does not fit the 16-bit packet length");
+        out.push_back(std::move(pkt));
+    }
+    return R::ok(std::move(out));
+}
+
+inline Result<FrameChunk> parseFrameChunk(const uint8_t* data, size_t size, Header* header_out = nullptr)
+{
+    using R = Result<FrameChunk>;
+    auto h = parseHeader(data, size, kTypeFrameChunk);
+    if (h.hasError()) return R::error(h.error());
+    if (header_out) *header_out = h.value();
+    const uint16_t length = h.value().length;
+    if (length < kChunkBodyHeader)
+        return R::error(ErrorCode::INVALID_PACKET, "Invalid frame chunk packet body length: expected at least " + std::to_string(kChunkBodyHeader) + ", got " + std::to_string(length));
+    const uint8_t* b = data + kHeaderSize;
+    FrameChunk c;
+    c.frame_id = detail::get<uint32_t>(b); c.timestamp = detail::get<uint64_t>(b + 4);
+    c.width = detail::get<uint16_t>(b + 12); c.height = detail::get<uint16_t>(b + 14);
+    c.keyframe = b[16] == 1;
+    c.index = detail::get<uint16_t>(b + 17); c.count = detail::get<uint16_t>(b + 19); c.offset = detail::get<uint32_t>(b + 21);
+    c.payload = b + kChunkBodyHeader; c.payload_size = (size_t)length - kChunkBodyHeader;
+    if (c.width == 0 || c.height == 0)
+        return R::error(ErrorCode::INVALID_PACKET, "Invalid frame dimensions: " + std::to_string(c.width) + "x" + std::to_string(c.height));
+    const size_t total = (size_t)c.width * c.height * 3;
+    if (c.count == 0 || c.index >= c.count || c.payload_size == 0 || (size_t)c.offset + c.payload_size > total)
+        return R::error(ErrorCode::INVALID_PACKET, "Invalid frame chunk: index " + std::to_string(c.index) + " of " + std::to_string(c.count) + ", bytes [" +
+                                                           std::to_string(c.offset) + ", " + std::to_string((size_t)c.offset + c.payload_size) + ") of " + std::to_string(total));
+    return R::ok(c);
+}
+
+// Reassembly per (client, frame_id).  Pieces may arrive in any order and more than once; a piece that contradicts the frame's first
+// piece (dimensions, count, timestamp) is refused.  At most `max_pending` incomplete frames are kept per client: UDP loses datagrams, and
+// a frame that lost one never completes -- the oldest incomplete frame makes room (counted in dropped()).
+class FrameAssembler {
+  public:
+    explicit FrameAssembler(size_t max_pending = 4) : max_pending_(max_pending ? max_pending : 1) {}
+
+    // -> true when this piece completed its frame (*out then holds it), false when more pieces are needed
+    Result<bool> add(uint32_t client_id, const FrameChunk& c, FrameData* out)
+    {
+        using R = Result<bool>;
+        std::deque<Partial>& q = pending_[client_id];
+        Partial* p = nullptr;
+        for (Partial& x : q) if (x.f.frame_id == c.frame_id) { p = &x; break; }
+        if (!p) {
+            if (q.size() >= max_pending_) { q.pop_front(); ++dropped_; }
+            q.emplace_back();
+            p = &q.back();
+            p->f.frame_id = c.frame_id; p->f.timestamp = c.timestamp; p->f.width = c.width; p->f.height = c.height; p->f.keyframe = c.keyframe;
+            p->f.data.assign((size_t)c.width * c.height * 3, 0);
+            p->have.assign(c.count, false);
+        } else if (p->f.width != c.width || p->f.height != c.height || p->have.size() != c.count || p->f.timestamp != c.timestamp) {
+            return R::error(ErrorCode::INVALID_PACKET, "frame chunk contradicts the earlier pieces of frame " + std::to_string(c.frame_id));
+        }
+        if (p->have[c.index]) return R::ok(false);                       // duplicate datagram
+        std::memcpy(p->f.data.data() + c.offset, c.payload, c.payload_size);
+        p->have[c.index] = true;
+        p->bytes += c.payload_size;
+        if (++p->got < p->have.size()) return R::ok(false);
+        if (p->bytes != p->f.data.size()) {                              // every index seen, yet the pieces do not tile the frame
+            const uint32_t id = c.frame_id;
+            erase(q, id);
+            return R::error(ErrorCode::INVALID_PACKET, "frame chunks of frame " + std::to_string(id) + " do not add up to width*height*3 bytes");
+        }
+        *out = std::move(p->f);
+        erase(q, c.frame_id);
+        return R::ok(true);
+    }
+    uint64_t dropped() const { return dropped_; }
+    size_t pending(uint32_t client_id) const { auto it = pending_.find(client_id); return it == pending_.end() ? 0 : it->second.size(); }
+
+  private:
+    struct Partial { FrameData f; std::vector<bool> have; size_t got = 0, bytes = 0; };
+    static void erase(std::deque<Partial>& q, uint32_t frame_id)
+    {
+        for (auto it = q.begin(); it != q.end(); ++it) if (it->f.frame_id == frame_id) { q.erase(it); return; }
+    }
+    size_t max_pending_;
+    std::map<uint32_t, std::deque<Partial>> pending_;
+    uint64_t dropped_ = 0;
+};
 
 }  // namespace wire
 }  // namespace zero_latency

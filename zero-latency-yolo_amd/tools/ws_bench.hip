@@ -1,0 +1,65 @@
+// ws_bench.hip -- DIAGNOSTIC build of conv3x3_ws_kernel with s_memtime stamps around its phases (never part of libzly.so).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Izero-latency-yolo_amd/csrc -DZLY_WS_DIAG=1 zero-latency-yolo_amd/tools/ws_bench.hip \
+//         -o zero-latency-yolo_amd/_build/ws_bench && ./zero-latency-yolo_amd/_build/ws_bench
+// Per layer shape: time of the launch(es) launch_conv would make, TFLOP/s, and the per-wave cycle sums of the three phases of a tile
+// (wait at the tile barrier | patch staging | column-tile loop: fragment reads + MFMAs + epilogue) against the bare MFMA cycles.
+#include "../csrc/kernels_conv.hip"
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+using namespace zly;
+
+static void run(const char* name, int n, int H, int W, int Cin, int Cout)
+{
+    const int nk = 9 * Cin / 32, cout_pad = (Cout + 15) / 16 * 16, ntiles = cout_pad / 16, even = ntiles / 2 * 2;
+    std::vector<uint16_t> hin((size_t)n * H * W * Cin), hw((size_t)cout_pad * nk * 32);
+    for (size_t i = 0; i < hin.size(); ++i) hin[i] = 0x3c00 + (uint16_t)((i * 2654435761u >> 20) & 0x1ff);
+    for (size_t i = 0; i < hw.size(); ++i) hw[i] = 0x3800 + (uint16_t)((i * 40503u >> 7) & 0x3ff) ^ ((i & 1) << 15);
+    void *din, *dw, *dout; float* dbias; unsigned long long* ddbg;
+    hipMalloc(&din, hin.size() * 2); hipMalloc(&dw, hw.size() * 2); hipMalloc(&dout, (size_t)n * H * W * Cout * 2);
+    hipMalloc((void**)&dbias, cout_pad * 4); hipMemset(dbias, 0, cout_pad * 4);
+    hipMemcpy(din, hin.data(), hin.size() * 2, hipMemcpyHostToDevice); hipMemcpy(dw, hw.data(), hw.size() * 2, hipMemcpyHostToDevice);
+    ConvArgs a; memset(&a, 0, sizeof a);
+    a.in = din; a.in_cs = Cin; a.H = H; a.W = W; a.Cin = Cin; a.wgt = dw; a.bias = dbias;
+    a.out = dout; a.out_cs = Cout; a.Ho = H; a.Wo = W; a.Cout = Cout; a.cout_pad = cout_pad; a.stride = 1; a.pad = 1;
+    a.K = 9 * Cin; a.nk = nk; a.M = n * H * W; a.act = 1;
+    WsGeom g{};
+    if (!ws_plan(H, W, Cin, &g)) { printf("%s: no plan\n", name); return; }
+    g.total_tiles = g.tiles_x * g.tiles_y * n;
+    const size_t lds = ((size_t)(g.TH + 2) * (g.TW + 2) * g.pitch + 15) / 16 * 16;
+    const int gx = g.total_tiles < 512 ? g.total_tiles : 512;
+    const size_t nw = (size_t)gx * 4;
+    hipMalloc((void**)&ddbg, nw * 64); hipMemset(ddbg, 0, nw * 64);
+    hipMemcpyToSymbol(HIP_SYMBOL(g_ws_diag), &ddbg, sizeof ddbg);
+    ws_init();
+    ConvLaunch cfg{}; cfg.ps = 1;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float ms = 0, best = 1e9f;
+    for (int rep = 0; rep < 30; ++rep) {
+        hipEventRecord(e0, 0);
+        launch_conv(ZLY_DTYPE_BF16, a, cfg, 0);
+        hipEventRecord(e1, 0); hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1);
+        if (rep >= 10 && ms < best) best = ms;
+    }
+    std::vector<unsigned long long> h(nw * 8);
+    hipMemcpy(h.data(), ddbg, nw * 64, hipMemcpyDeviceToHost);          // stamps of the LAST kernel launched (the odd-tile launch when there is one)
+    double s[4] = {0}; for (size_t w = 0; w < nw; ++w) for (int k = 0; k < 4; ++k) s[k] += (double)h[w * 8 + k];
+    const double tpw = (double)g.total_tiles / gx;
+    const double gflop = 2.0 * n * H * W * (double)Cout * 9 * Cin / 1e9;
+    const int nct = (g.TH * g.TW + 15) / 16, nwc = (ntiles > even ? 1 : even / 2), nwp = 4 / nwc, tiles_w = ntiles > even ? 1 : 2;
+    printf("%-30s tile %dx%d (%d column tiles) lds=%zuKB grid %d%s: %.1f us best of 20 (%.0f TFLOP/s)  last launch, cycles/tile/wave: barrier %.0f  patch %.0f  loop %.0f | wave total %.0f per tile (bare MFMA %d)\n",
+           name, g.TH, g.TW, nct, lds / 1024, gx, ntiles > even ? " + odd-tile launch" : "", best * 1e3, gflop / (best * 1e-3) / 1e3,
+           s[0] / nw / tpw, s[1] / nw / tpw, s[2] / nw / tpw, s[3] / nw / tpw, (nct + nwp - 1) / nwp * tiles_w * nk * 16);
+    hipFree(din); hipFree(dw); hipFree(dout); hipFree(dbias); hipFree(ddbg);
+}
+
+int main()
+{
+    run("52x52 64->64 (x64) P3 box2", 64, 52, 52, 64, 64);
+    run("52x52 64->128 (x64)", 64, 52, 52, 64, 128);
+    run("52x52 64->144 (x64) P3 stem", 64, 52, 52, 64, 144);
+    run("26x26 64->64 (x64)", 64, 26, 26, 64, 64);
+    run("52x52 64->32 (x64)", 64, 52, 52, 64, 32);
+    return 0;
+}
