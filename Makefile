@@ -16,7 +16,7 @@ KERNELS  := $(CSRC)/kernels_conv.hip $(CSRC)/kernels_pair.hip $(CSRC)/kernels_mi
 ENGINE   := $(CSRC)/engine.cpp $(CSRC)/weights.cpp
 OBJS     := $(OUT)/kernels_conv.o $(OUT)/kernels_pair.o $(OUT)/kernels_misc.o $(OUT)/kernels_head.o $(OUT)/kernels_stem.o $(OUT)/kernels_post.o $(OUT)/engine.o $(OUT)/weights.o
 
-all: $(OUT)/libzly.so oracle weights host
+all: $(OUT)/libzly.so $(OUT)/libzly_gather.so $(OUT)/test_gather oracle weights host
 
 $(OUT):
 	mkdir -p $(OUT)
@@ -33,8 +33,16 @@ $(OUT)/weights.o: $(CSRC)/weights.cpp $(CSRC)/weights.h include/zly.h | $(OUT)
 $(OUT)/libzly.so: $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
 
+# ---- in-process RCCL gather of result slabs (include/zly_gather.h): a library of its own -- it links RCCL, and a process that already carries
+#      PyTorch's bundled RCCL (bench.py, the tests) must never load a second one
+$(OUT)/libzly_gather.so: $(CSRC)/gather.cpp include/zly_gather.h | $(OUT)
+	$(HIPCC) --offload-arch=$(ARCH) -O2 -std=c++17 -fPIC -shared -Iinclude -x hip $(CSRC)/gather.cpp -o $@ -L/opt/rocm/lib -lrccl
+
+$(OUT)/test_gather: tests/cpp/test_gather.cpp $(OUT)/libzly_gather.so $(OUT)/libzly.so
+	$(HIPCC) --offload-arch=$(ARCH) -O2 -std=c++17 -Wno-unused-value -Iinclude -x hip tests/cpp/test_gather.cpp -o $@ -L$(OUT) -lzly_gather -lzly -Wl,-rpath,'$$ORIGIN'
+
 # ---- host side: the reference's IInferenceEngine plugin interface over the C ABI -----------------
-host: $(OUT)/libzly_plugin.so $(OUT)/test_hip_engine $(OUT)/test_wire $(OUT)/test_game_step $(OUT)/test_frame_server $(OUT)/zly_h2h_bench
+host: $(OUT)/libzly_plugin.so $(OUT)/test_hip_engine $(OUT)/test_wire $(OUT)/test_game_step $(OUT)/test_frame_server $(OUT)/zly_h2h_bench $(OUT)/test_plugin_stub
 
 $(OUT)/libzly_plugin.so: $(HOST)/hip_inference_engine.cpp $(HOST)/hip_inference_engine.h $(HOST)/zly_sha256.hpp $(HOST)/zly_compat.hpp include/zly.h $(OUT)/libzly.so
 	$(CXX) -O2 -std=c++17 -fPIC -shared -Iinclude -I$(HOST) -o $@ $(HOST)/hip_inference_engine.cpp -L$(OUT) -lzly -pthread -Wl,-rpath,'$$ORIGIN'
@@ -47,6 +55,10 @@ $(OUT)/zly_h2h_bench: $(PKG)/tools/bench_h2h.cpp $(OUT)/libzly_plugin.so
 
 $(OUT)/test_frame_server: tests/cpp/test_frame_server.cpp $(HOST)/zly_frame_server.hpp $(HOST)/zly_wire.hpp $(HOST)/zly_game_step.hpp $(OUT)/libzly_plugin.so
 	$(CXX) -O2 -std=c++17 -Wall -Iinclude -I$(HOST) -o $@ tests/cpp/test_frame_server.cpp -Wl,--no-as-needed -L$(OUT) -lzly_plugin -lzly -pthread -Wl,-rpath,'$$ORIGIN'
+
+# the plugin's host logic against a link-time stub of the C ABI (test infrastructure: no libzly.so, no GPU)
+$(OUT)/test_plugin_stub: tests/cpp/test_plugin_stub.cpp $(HOST)/hip_inference_engine.cpp $(HOST)/hip_inference_engine.h $(HOST)/zly_compat.hpp include/zly.h | $(OUT)
+	$(CXX) -O2 -std=c++17 -Wall -Iinclude -I$(HOST) -o $@ tests/cpp/test_plugin_stub.cpp -pthread
 
 $(OUT)/test_wire: tests/cpp/test_wire.cpp $(HOST)/zly_wire.hpp $(HOST)/zly_sha256.hpp $(HOST)/zly_compat.hpp | $(OUT)
 	$(CXX) -O2 -std=c++17 -Wall -I$(HOST) -o $@ tests/cpp/test_wire.cpp

@@ -127,6 +127,8 @@ typedef struct zly_stats {
     uint64_t sampled_frames;
     double sampled_preprocess_ms, sampled_forward_ms, sampled_postprocess_ms;
     uint64_t batches;                                                     /* calls of a detect path (any entry point) */
+    uint64_t graph_replays;                                               /* of them: forward replayed as a captured hipGraph ... */
+    uint64_t eager_batches;                                               /* ... or launched kernel by kernel (partial batches of the pipelined path, use_graph = 0, a capture that failed twice) */
 } zly_stats;
 
 typedef struct zly_op_info {

@@ -1,0 +1,39 @@
+"""In-process RCCL gather of result slabs (include/zly_gather.h, libzly_gather.so): SURVEY 8e's exchange step for the single-process,
+several-GPUs server (the plugin's ZLY_NUM_DEVICES mode).  CPU: the library exports what its header declares and fails cleanly
+without a device.  GPU: tests/cpp/test_gather.cpp runs engines + zly_join + ncclAllGather over the devices of the box (world 1 on the
+one-GPU test boxes) and the gathered bytes must be the engines' own slabs, rank-major.  The library is never loaded into a Python
+process (PyTorch carries its own RCCL): both tests go through separate binaries / a bare ctypes handle without torch's nccl."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BUILD = os.path.join(ROOT, "zero-latency-yolo_amd", "_build")
+
+
+def test_gather_header_and_library_agree():
+    hdr = open(os.path.join(ROOT, "include", "zly_gather.h")).read()
+    declared = set(re.findall(r"\b(zly_gather_[a-z_]+)\s*\(", hdr))
+    assert declared == {"zly_gather_create", "zly_gather_all", "zly_gather_ndev", "zly_gather_destroy", "zly_gather_last_error"}
+    lib_path = os.path.join(BUILD, "libzly_gather.so")
+    if not os.path.exists(lib_path):
+        subprocess.run(["make", "-C", ROOT, os.path.relpath(lib_path, ROOT)], check=True, stdout=subprocess.DEVNULL)
+    # symbols only (nm): the library is not dlopen()ed here -- it would bring a second RCCL next to PyTorch's into the test process
+    out = subprocess.run(["nm", "-D", "--defined-only", lib_path], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r"\bT (zly_gather_[a-z_]+)", out))
+    assert declared == exported, declared ^ exported
+
+
+@pytest.mark.gpu
+def test_gathered_slabs_equal_engine_slabs(tmp_path, weights_path):
+    exe = os.path.join(BUILD, "test_gather")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", ROOT, os.path.relpath(exe, ROOT)], check=True, stdout=subprocess.DEVNULL)
+    rep_path = tmp_path / "report.txt"
+    r = subprocess.run([exe, weights_path, str(rep_path)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stderr[-800:])
+    rep = dict(line.split("=", 1) for line in rep_path.read_text().splitlines())
+    assert int(rep["devices"]) >= 1 and rep["gathered_equals_engine_slabs"] == "1" and rep["tags_ok"] == "1" and int(rep["detections"]) > 0

@@ -99,7 +99,10 @@ def _rand_head(rng, nc, n, hot=0.02, size=416):
 
 
 @pytest.mark.parametrize("nc,n,hot,seed", [(80, 3549, 0.02, 0), (80, 3549, 0.2, 1), (4, 8400, 0.05, 2), (1, 1000, 0.3, 3),
-                                           (80, 3549, 0.6, 4), (3, 777, 0.1, 5), (80, 64, 0.5, 6)])
+                                           (80, 3549, 0.6, 4), (3, 777, 0.1, 5), (80, 64, 0.5, 6),
+                                           # the one-wave NMS path (<= 128 candidates, two per lane) at its edges: 64 / 65 / 128 candidates, one class
+                                           # (every box can suppress every later one) and many; 129 falls to the eight-wave path
+                                           (1, 64, 1.0, 7), (5, 65, 1.0, 8), (1, 128, 1.0, 9), (80, 128, 1.0, 10), (2, 129, 1.0, 11), (3, 1, 1.0, 12)])
 def test_postprocess_bit_exact(eng16, oracle, nc, n, hot, seed):
     head = _rand_head(np.random.default_rng(seed), nc, n, hot)
     want = oracle.postprocess(head, 800, 600)

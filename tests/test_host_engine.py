@@ -47,6 +47,33 @@ def test_plugin_registers_and_fails_loudly_without_gpu(tmp_path, weights_path):
     assert j["init"] in (0, 300)
 
 
+def test_plugin_multi_engine_host_logic_with_stub_engines(tmp_path):
+    """CPU-runnable: the plugin's host logic for several engines per process (ZLY_NUM_DEVICES=2 x ZLY_ENGINES_PER_GPU=2), compiled together
+    with a link-time stub of the C-ABI calls it makes (tests/cpp/test_plugin_stub.cpp: test infrastructure, not a product fallback).
+    Fake engines finish out of order; the callbacks must still arrive in submission order, one per good frame, round-robin over the four
+    engine handles (two per device), with wrong-sized frames counted and skipped; a hot reload under load moves new requests to the new
+    engines while requests in flight finish on the old ones, which are destroyed on the reaper thread -- never on the completion thread
+    that delivers callbacks; a failing reload leaves the running engines in place."""
+    stub = os.path.join(ROOT, "zero-latency-yolo_amd", "_build", "test_plugin_stub")
+    if not os.path.exists(stub):
+        subprocess.run(["make", "-C", ROOT, "host"], check=True, stdout=subprocess.DEVNULL)
+    rep_path = tmp_path / "report.txt"
+    r = subprocess.run([stub, str(rep_path)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    rep = dict(line.split("=", 1) for line in rep_path.read_text().splitlines())
+    assert rep["created"] == "4" and rep["devices"] == "0,0,1,1,"                        # two engines on each of two devices
+    assert rep["phase1_all"] == "1" and rep["phase1_count"] == "58"                      # 64 frames, 6 with a wrong byte count
+    assert rep["phase1_in_order"] == "1" and rep["phase1_round_robin"] == "1" and rep["phase1_echo"] == "1" and rep["phase1_callback_threads"] == "1"
+    assert rep["status_errors"] == "6" and rep["status_count"] == "58"
+    assert (rep["status_devices"], rep["status_engines_per_gpu"], rep["status_worker_threads"]) == ("2", "2", "4")
+    assert rep["phase2_all"] == "1" and rep["phase2_count"] == "200" and rep["phase2_per_client_order"] == "1"
+    assert rep["phase2_on_old_engines"] == "1" and rep["phase2_on_new_engines"] == "1"   # the reload happened under load
+    assert rep["created_after_reload"] == "8" and rep["destroyed_after_reload"] == "4" and rep["destroyed_on_completion_thread"] == "0"
+    assert rep["model_version"] == "2"
+    assert rep["failed_reload_code"] == "202" and rep["model_version_after_failed_reload"] == "2" and rep["served_after_failed_reload"] == "1"
+    assert rep["submit_after_shutdown"] == "3" and rep["created_total"] == rep["destroyed_total"] == "9"
+
+
 @pytest.mark.gpu
 def test_host_engine_matches_c_abi_and_oracle(tmp_path, weights_path, oracle):
     import zly
@@ -139,6 +166,10 @@ def test_host_engine_hot_reload(tmp_path, weights_path):
     assert j["status_after_reload"]["model_hash"] == hashlib.sha256(new_w.read_bytes()).hexdigest()
     assert j["reload_bad_file"] == 202 and j["version_after_bad_file"] == "2"          # MODEL_LOAD_FAILED, old engines keep serving
     assert [x["frame_id"] for x in j["results_after_reload"]] == [100 + i for i in range(5)]
+    # graphs are captured at zly_create (batch 1 and max_batch), under the process-wide exclusive gate, also for the engines a reload builds
+    # beside the running ones: the frames served after the reload are graph replays on the NEW engines, none fell back to eager launches
+    assert int(j["status"]["graph_replays"]) >= 5 and int(j["status"]["eager_batches"]) == 0
+    assert int(j["status_after_reload"]["graph_replays"]) >= 5 and int(j["status_after_reload"]["eager_batches"]) == 0
 
     def unpack(x):
         got = np.zeros(len(x["dets"]), dtype=zly.DET_DTYPE)

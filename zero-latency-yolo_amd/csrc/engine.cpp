@@ -497,7 +497,7 @@ static int build_plan(zly_engine* e, std::string* err)
         hl.box_cs = c2; hl.cls_cs = c3; hl.box_cin = c2; hl.cls_cin = c3;
         hl.H = fh[l]; hl.W = fw[l]; hl.hw = fh[l] * fw[l]; hl.stride_px = 8 << l; hl.anchor_off = anchor_off; hl.block0 = block0;
         hl.logits_cs = 64 + ncp;
-        block0 += (hl.hw + 63) / 64;
+        block0 += (hl.hw + HEAD_GROUP - 1) / HEAD_GROUP;
         const double macs = (double)hl.hw * (c2 * 64.0 + (double)c3 * m.nc);
         hd.flops += 2.0 * macs;
         // algorithmic bytes: both branch activations in, the weights, and -- only when the engine materialises it -- the fp32 head tensor out
@@ -1052,8 +1052,10 @@ static int run_path(zly_engine* e, int n, const uint8_t* d_src, void* d_slabs_ou
     }
     if (e->cfg.use_graph && git != e->graphs.end() && git->second) {
         HIP_TRY(hipGraphLaunch(git->second, s), ZLY_ERR_INFERENCE);
+        with_stats(e, [](zly_stats& st) { st.graph_replays++; });
     } else {
         HIP_TRY(run_ops(e, first, nops - 1, n, nullptr, nullptr, 0, s), ZLY_ERR_INFERENCE);
+        with_stats(e, [](zly_stats& st) { st.eager_batches++; });
     }
     if (sample) HIP_TRY(hipEventRecord(e->ev_t[2], s), ZLY_ERR_INFERENCE);
     hipStream_t ns = s;

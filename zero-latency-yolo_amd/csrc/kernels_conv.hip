@@ -861,7 +861,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ws_kernel(const ConvArgs a, co
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* lpatch = smem;
-    const int PW = g.TW + 2, PH = g.TH + 2;
+    // patch rows are TW + 8 pixels apart although only TW + 2 are used: bank(pixel) repeats every 8 pixels at a pitch of 160 bytes, so a
+    // 16-pixel column tile that wraps into the next row (most do at TW = 13) then hits the same banks as 16 consecutive pixels would:
+    // conflict-free fragment reads (with PW = TW + 2 three of four reads took 8 LDS cycles instead of 4, and with 18 reads per 36 MFMAs
+    // and 8 waves per CU the LDS, not the matrix pipe, set the pace: profiles/r03_ws_kernel_phase_stamps_v2.txt)
+    const int PW = g.TW + 8, PH = g.TH + 2;
     const int nthreads = blockDim.x;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -909,63 +913,88 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ws_kernel(const ConvArgs a, co
 #define WSPHASE(k) do { } while (0)
 #endif
 
+    // Patch staging by LDS-DMA (buffer_load ... lds: no staging registers, no ds_write, asynchronous): wave-instruction k fills the 1 KiB
+    // of LDS units [64 k, 64 k + 64); lane -> unit u -> (patch pixel, 16-byte piece); the pieces beyond the pixel's channels (the pitch
+    // padding), pixels outside the frame (the conv's zero padding) and units beyond the patch get an out-of-range offset: the buffer
+    // range check returns zeros.
+    const int upitch = g.pitch >> 4;                             // 16-byte units per patch pixel incl. padding
+    const int NLU = PH * PW * upitch, ndma = (NLU + 63) >> 6;
+    const float inv_upitch = 1.0f / (float)upitch;
+    const int patch_bytes = ndma * 1024;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(in), 0, (unsigned)(((size_t)a.M / (a.Ho * a.Wo) * a.H * a.W * a.in_cs - a.in_co) * 2), 0x00020000);
+    auto dma_patch = [&](int tl, unsigned char* dst) {
+        const int b = tl / tiles_per_img;
+        const int r = tl - b * tiles_per_img;
+        const int ty = r / g.tiles_x;
+        const int y0 = ty * g.TH, x0 = (r - ty * g.tiles_x) * g.TW;
+        for (int k = wave; k < ndma; k += nthreads >> 6) {
+            const int u = k * 64 + lane;
+            const int px = (int)(((float)u + 0.5f) * inv_upitch), part = u - px * upitch;
+            const int py = (int)(((float)px + 0.5f) * invPW), pxx = px - py * PW;
+            const int gy = y0 - 1 + py, gx = x0 - 1 + pxx;
+            const bool ok = part < upp && pxx < g.TW + 2 && py < PH && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+            const unsigned off = ok ? (unsigned)((((b * a.H + gy) * a.W + gx) * a.in_cs) * 2 + part * 16) : 0x80000000u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)(dst + k * 1024), 16, off, 0, 0, 0);
+        }
+    };
+    (void)NPU; (void)inv_upp; (void)patch_bytes;
+    if ((int)blockIdx.x < g.total_tiles) dma_patch(blockIdx.x, lpatch);
     for (int tl = blockIdx.x; tl < g.total_tiles; tl += gridDim.x) {
         const int b = tl / tiles_per_img;
         const int r = tl - b * tiles_per_img;
         const int ty = r / g.tiles_x;
         const int y0 = ty * g.TH, x0 = (r - ty * g.tiles_x) * g.TW;
-        __syncthreads();                                        // the previous tile's readers of the patch are done
+        unsigned char* cur = lpatch;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's pieces of the patch have landed (and its stores of the previous tile are out)
+        __syncthreads();                                        // everybody's have
         WSPHASE(0);
-        // ---- input patch: global -> LDS, zero outside the frame (the conv's padding) ----------------------------------------------
-        for (int u0 = 0; u0 < NPU; u0 += nthreads * 4) {
-            u32x4 v[4];
+        // ---- this wave's column tiles: wp, wp + nwp, ... two at a time (independent accumulators and fragment streams: a lone wave per
+        //      workgroup and SIMD has nothing else to cover the ds_read latency and the previous pair's epilogue with) ----------------------
+        for (int t0 = wp; t0 < nct; t0 += 2 * g.nwp) {
+            const unsigned char* px[2];
+            int qq[2], gyy[2], gxx[2];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int u = u0 + i * nthreads + tid;
-                v[i] = u32x4{0u, 0u, 0u, 0u};
-                if (u < NPU) {
-                    const int px = (int)(((float)u + 0.5f) * inv_upp), part = u - px * upp;
-                    const int py = (int)(((float)px + 0.5f) * invPW), pxx = px - py * PW;
-                    const int gy = y0 - 1 + py, gx = x0 - 1 + pxx;
-                    if ((unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W)
-                        v[i] = *reinterpret_cast<const u32x4*>(in + ((size_t)(b * a.H + gy) * a.W + gx) * a.in_cs + part * 8);
-                }
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int t = min(t0 + h2 * g.nwp, nct - 1);
+                qq[h2] = (t0 + h2 * g.nwp < nct) ? t * 16 + p : NPB;              // a missing second tile: computed on a copy of the last, never stored
+                const int qc = min(t * 16 + p, NPB - 1);
+                const int oy = (int)(((float)qc + 0.5f) * invTW), ox = qc - oy * g.TW;
+                px[h2] = cur + (oy * PW + ox) * g.pitch + kq * 16;
+                gyy[h2] = y0 + oy; gxx[h2] = x0 + ox;
             }
+            f32x4 acc[2][TPW];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int u = u0 + i * nthreads + tid;
-                if (u < NPU) {
-                    const int px = (int)(((float)u + 0.5f) * inv_upp), part = u - px * upp;
-                    *reinterpret_cast<u32x4*>(lpatch + px * g.pitch + part * 16) = v[i];
-                }
-            }
-        }
-        __syncthreads();
-        WSPHASE(1);
-        // ---- this wave's column tiles: wp, wp + nwp, ... ----------------------------------------------------------------------------
-        for (int t = wp; t < nct; t += g.nwp) {
-            const int q = t * 16 + p;
-            const int qc = min(q, NPB - 1);
-            const int oy = (int)(((float)qc + 0.5f) * invTW), ox = qc - oy * g.TW;
-            const unsigned char* px = lpatch + (oy * PW + ox) * g.pitch + kq * 16;
-            f32x4 acc[TPW];
+            for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
-            for (int c = 0; c < TPW; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-            // pixel fragments are read WS_DEPTH k-steps ahead of the MFMAs that consume them (statically indexed ring)
-            constexpr int WS_DEPTH = 4;
-            bf16x8 xf[WS_DEPTH + 1];
+                for (int c = 0; c < TPW; ++c) acc[h2][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // pixel fragments are read WS_DEPTH k-steps ahead of the MFMAs that consume them (statically indexed rings)
+            constexpr int WS_DEPTH = 3;
+            bf16x8 xf[2][WS_DEPTH + 1];
 #pragma unroll
-            for (int s = 0; s < WS_DEPTH; ++s) xf[s] = *reinterpret_cast<const bf16x8*>(px + toff[s]);
+            for (int s = 0; s < WS_DEPTH; ++s) { xf[0][s] = *reinterpret_cast<const bf16x8*>(px[0] + toff[s]); xf[1][s] = *reinterpret_cast<const bf16x8*>(px[1] + toff[s]); }
 #pragma unroll
             for (int s = 0; s < NKS; ++s) {
-                if (s + WS_DEPTH < NKS) xf[(s + WS_DEPTH) % (WS_DEPTH + 1)] = *reinterpret_cast<const bf16x8*>(px + toff[s + WS_DEPTH]);
+                if (s + WS_DEPTH < NKS) {
+                    xf[0][(s + WS_DEPTH) % (WS_DEPTH + 1)] = *reinterpret_cast<const bf16x8*>(px[0] + toff[s + WS_DEPTH]);
+                    xf[1][(s + WS_DEPTH) % (WS_DEPTH + 1)] = *reinterpret_cast<const bf16x8*>(px[1] + toff[s + WS_DEPTH]);
+                }
 #pragma unroll
-                for (int c = 0; c < TPW; ++c) acc[c] = mma_step(w[c][s], xf[s % (WS_DEPTH + 1)], acc[c]);
+                for (int c = 0; c < TPW; ++c) {
+                    acc[0][c] = mma_step(w[c][s], xf[0][s % (WS_DEPTH + 1)], acc[0][c]);
+                    acc[1][c] = mma_step(w[c][s], xf[1][s % (WS_DEPTH + 1)], acc[1][c]);
+                }
             }
-            const int gy = y0 + oy, gx = x0 + ox;
-            if (q < NPB && gy < a.Ho && gx < a.Wo) epilogue_px_buf<TPW>(a, rout, rres, acc, biasr, wc * TPW, kq, (b * a.Ho + gy) * a.Wo + gx);
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2)
+                if (qq[h2] < NPB && gyy[h2] < a.Ho && gxx[h2] < a.Wo)
+                    epilogue_px_buf<TPW>(a, rout, rres, acc[h2], biasr, wc * TPW, kq, (b * a.Ho + gyy[h2]) * a.Wo + gxx[h2]);
         }
         WSPHASE(2);
+        if (tl + (int)gridDim.x < g.total_tiles) {
+            __syncthreads();                                    // everybody is done reading the patch: the next tile's may land (the other resident workgroup computes meanwhile)
+            dma_patch(tl + gridDim.x, lpatch);
+        }
+        WSPHASE(1);
     }
 #ifdef ZLY_WS_DIAG
     if (lane == 0 && g_ws_diag) {
@@ -982,23 +1011,23 @@ static conv_ws_fn pick_ws(int cin, int tpw)
     if (cin != 64) return nullptr;
     return tpw == 2 ? conv3x3_ws_kernel<2, 18> : conv3x3_ws_kernel<1, 18>;
 }
-static constexpr int WS_LDS_MAX = 80 * 1024;
+static constexpr int WS_LDS_MAX = 64 * 1024;        // two resident workgroups per CU with room to spare (two of exactly 80 KB did not both become resident)
 
-// tile shape: among the shapes whose patch fits the 80 KB of one of two resident workgroups, the one that needs the fewest tiles, then
-// computes the fewest pixels beyond the map, then has the smallest patch
-static bool ws_plan(int H, int W, int cin, WsGeom* g)
+// tile shape: among the shapes whose patch lets two workgroups be resident per CU, the one with the least work on the busiest workgroup --
+// rounds of tiles over the 2 x 256 resident workgroups x (pixels of a tile + a fixed per-tile cost); 768 tiles of 9 x 26 lose to 1024 of 13 x 13
+static bool ws_plan(int H, int W, int cin, int n, WsGeom* g)
 {
     if (!pick_ws(cin, 2)) return false;
     const int pitch = cin * 2 + 32;
     long best = -1;
     for (int th = 4; th <= 32; ++th)
         for (int tw = 8; tw <= 32; ++tw) {
-            const long lds = ((long)(th + 2) * (tw + 2) * pitch + 15) / 16 * 16;
+            const long lds = ((long)(th + 2) * (tw + 8) * pitch + 1023) / 1024 * 1024;
             if (lds > WS_LDS_MAX) continue;
             const int tx = (W + tw - 1) / tw, ty = (H + th - 1) / th;
-            const long tiles = (long)tx * ty;
-            const long waste = (long)tx * tw * ty * th - (long)H * W;
-            const long key = (tiles * 100000 + waste) * 2000 + (th + 2) * (tw + 2);
+            const long tiles = (long)tx * ty * n;
+            const long rounds = (tiles + 2 * num_cus() - 1) / (2 * num_cus());
+            const long key = rounds * ((th * tw + 15) / 16 * 16 + 64) * 4096 + (th + 2) * (tw + 8);
             if (best < 0 || key < best) { best = key; g->TH = th; g->TW = tw; g->tiles_x = tx; g->tiles_y = ty; }
         }
     if (best < 0) return false;
@@ -1128,11 +1157,12 @@ static bool pick_ws_config(int stride, int cin, int cout_pad, int n, int Ho, int
     const int even = cout_pad / 16 / 2 * 2;                         // tiles of the TPW = 2 launch; an odd last tile goes to a TPW = 1 launch
     if (off || stride != 1 || cout_pad % 16 || (even != 2 && even != 4 && even != 8)) return false;
     WsGeom g{};
-    if (!ws_plan(Ho, Wo, cin, &g)) return false;
-    const long tiles = (long)n * g.tiles_x * g.tiles_y;
+    if (!ws_plan(Ho, Wo, cin, n, &g)) return false;
+    // enough pixels to give each of the 512 resident workgroups a ~13 x 13 tile (the tile planner would happily cut a small launch into
+    // tiny tiles): below that the launch belongs to the latency-path kernels
     const double util = (double)Ho * Wo / ((double)g.tiles_x * g.tiles_y * g.TH * g.TW);
     const char* mt = getenv("ZLY_WS_MIN_TILES");
-    if (util < 0.7 || tiles < (mt ? atol(mt) : 256)) return false;
+    if (util < 0.7 || (long)n * Ho * Wo < (mt ? atol(mt) : 256) * 169L) return false;
     cfg->ps = 1; cfg->ct = cout_pad / 16; cfg->pt = 4; cfg->ksplit = 1; cfg->fastk = 1;
     return true;
 }
@@ -1192,10 +1222,10 @@ hipError_t launch_conv(int dtype, const ConvArgs& a, const ConvLaunch& cfg, hipS
         WsGeom g{};
         const int ntiles = a.cout_pad / 16, even = ntiles / 2 * 2;
         if (dtype != ZLY_DTYPE_BF16 || !pick_ws(a.Cin, 2) || a.stride != 1 || a.pad != 1 || a.in2 || a.out_f32 || a.nk != 9 * a.Cin / 32 ||
-            a.in_cs % 8 || a.in_co % 8 || (even != 2 && even != 4 && even != 8) || !ws_plan(a.Ho, a.Wo, a.Cin, &g)) return hipErrorInvalidValue;
+            a.in_cs % 8 || a.in_co % 8 || (even != 2 && even != 4 && even != 8) || !ws_plan(a.Ho, a.Wo, a.Cin, a.M / (a.Ho * a.Wo), &g)) return hipErrorInvalidValue;
         const int n = a.M / (a.Ho * a.Wo);
         g.total_tiles = g.tiles_x * g.tiles_y * n;
-        const size_t lds = ((size_t)(g.TH + 2) * (g.TW + 2) * g.pitch + 15) / 16 * 16;
+        const size_t lds = ((size_t)(g.TH + 2) * (g.TW + 8) * g.pitch + 1023) / 1024 * 1024;
         const int gx = g.total_tiles < 2 * num_cus() ? g.total_tiles : 2 * num_cus();      // persistent: two resident workgroups per CU
         // the even tiles: 4 waves = (even / 2) channel groups x pixel groups
         ConvArgs m = a;

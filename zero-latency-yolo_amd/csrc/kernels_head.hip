@@ -43,13 +43,23 @@ template <typename T> __device__ __forceinline__ float h_div(float a, float b);
 template <> __device__ __forceinline__ float h_div<float>(float a, float b) { return a / b; }
 template <> __device__ __forceinline__ float h_div<bf16_t>(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
 
-// One wave = 16 anchors (MFMA columns).  Lane (p = lane & 15, kq = lane >> 4) ends up holding, for
-// every 16-channel tile c, channels c*16 + kq*4 + {0..3} of anchor p.
+// A workgroup (HEAD_WAVES = 8 waves) owns HEAD_GROUP = 128 consecutive anchors of one level of one frame, one wave per 16 anchors (MFMA
+// columns): lane (p = lane & 15, kq = lane >> 4) ends up holding, for every 16-channel tile c, channels c*16 + kq*4 + {0..3} of anchor p.
+// What the ablation showed (tools/head_bench.hip, profiles/r03_head_kernel_ablation.txt; 36.6 us for the batch-64 tail): 11.5 us are the
+// 56 832 four-wave... one-tile waves themselves (dispatch + set-up), ~8 us each the weight fragments (23 KiB per wave through L1) and the
+// activations, ~10 us the epilogue.  So: the level's two weight matrices go to LDS once per workgroup (23 KiB per 128 anchors instead of
+// per 16) and the fragments come from there; the class-branch activations are requested BEFORE the weight staging and its barrier, so
+// they are in flight meanwhile; and the epilogue is skipped where it cannot matter:
+// Early out (production: no head tensor, no logit dump): when NO anchor of the tile has a class logit above skip_logit =
+// logit(conf_thr) - 1e-2, none can reach the confidence threshold (the margin is four orders of magnitude above the error of
+// v_exp / v_rcp), and the box loads, the box GEMM, the DFL and the 80 sigmoids per anchor are skipped -- ~4 of 5 tiles on a detector that
+// passes ~1.5 % of its anchors.  Tiles that are not skipped run the full arithmetic, so the candidates are exactly the same.
 template <typename T, int CTC>
-__global__ __launch_bounds__(256) void head_fused_kernel(const HeadArgs a)
+__global__ __launch_bounds__(HEAD_WAVES * 64) void head_fused_kernel(const HeadArgs a)
 {
     typedef typename HFrag<T>::type F;
     constexpr int EPL = HFrag<T>::EPL, KSTEP = HFrag<T>::KSTEP, WTILE = 16 * KSTEP;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int p = lane & 15, kq = lane >> 4;
@@ -57,62 +67,60 @@ __global__ __launch_bounds__(256) void head_fused_kernel(const HeadArgs a)
     const int bx = blockIdx.x + (a.only_level >= 0 ? a.lv[a.only_level].block0 : 0);
     const int li = bx >= a.lv[2].block0 ? 2 : (bx >= a.lv[1].block0 ? 1 : 0);
     const HeadLevel& L = a.lv[li];
-    const int anchor0 = (bx - L.block0) * 64 + wave * 16;
-    if (anchor0 >= L.hw) return;                           // wave-uniform; no barriers in this kernel
+    const int anchor0 = (bx - L.block0) * HEAD_GROUP + wave * 16;
+    const bool active = anchor0 < L.hw;                    // wave-uniform; inactive waves still help staging the weights
     const int an = anchor0 + p;
-    const bool valid = an < L.hw;
+    const bool valid = active && an < L.hw;
     const size_t pix = (size_t)f * L.hw + (valid ? an : 0);
 
     F zero;
 #pragma unroll
     for (int j = 0; j < EPL; ++j) zero[j] = (T)0.0f;
 
-    // All fragments of the tile -- both branches, every k-step -- are requested before the first MFMA: with the loads inside the k-step loops
-    // (trip counts are run-time values) every k-step exposed one memory round trip, five per wave, and a wave lived 19 k cycles of which
-    // 60 % in s_waitcnt (PMC, profiles/r02_final_pmc_kernels.txt): 42 us per batch-64 step for 65 MB.
+    // class-branch fragments of the tile, every k-step, requested up front
     constexpr int KMAX = 8;                                  // k-steps of a branch: bf16 80/128 channels -> 3/4, fp32 -> 5/8
-    F xb[KMAX], xc[KMAX];
+    F xc[KMAX];
     {
-        const T* pb = static_cast<const T*>(L.box_in) + pix * L.box_cs;
         const T* pc = static_cast<const T*>(L.cls_in) + pix * L.cls_cs;
 #pragma unroll
         for (int s = 0; s < KMAX; ++s) {
             const int ci = s * KSTEP + kq * EPL;
-            xc[s] = zero; xb[s] = zero;
-#ifdef ZLY_HEAD_DIAG
-            if (a.diag & 2) continue;                              // diagnostic: no activation loads
-#endif
+            xc[s] = zero;
             if (s < L.nkc && valid && ci < L.cls_cin) xc[s] = *reinterpret_cast<const F*>(pc + ci);
-            if (s < L.nkb && valid && ci < L.box_cin) xb[s] = *reinterpret_cast<const F*>(pb + ci);
         }
     }
+    // weights -> LDS: [box: 4 x nkb tiles][class: CTC x nkc tiles], 1 KiB each, already in MFMA lane order
+    T* lwb = reinterpret_cast<T*>(smem);
+    T* lwc = lwb + (size_t)4 * L.nkb * WTILE;
+    {
+        const int nb16 = 4 * L.nkb * 64, nc16 = CTC * L.nkc * 64;          // 16-byte units
+        const uint4* gb = reinterpret_cast<const uint4*>(L.wb);
+        const uint4* gc = reinterpret_cast<const uint4*>(L.wc);
+        uint4* sb4 = reinterpret_cast<uint4*>(lwb);
+        uint4* sc4 = reinterpret_cast<uint4*>(lwc);
+        for (int u = threadIdx.x; u < nb16; u += HEAD_WAVES * 64) sb4[u] = gb[u];
+        for (int u = threadIdx.x; u < nc16; u += HEAD_WAVES * 64) sc4[u] = gc[u];
+    }
+    __syncthreads();
+    if (!active) return;
+
     // ---- class branch: [nc x cin] . [cin x 16] ---------------------------------------------------
     f32x4 accc[CTC];
 #pragma unroll
     for (int c = 0; c < CTC; ++c) accc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
     {
-        const T* w = static_cast<const T*>(L.wc) + lane * EPL;
+        const T* w = lwc + lane * EPL;
 #pragma unroll
         for (int s = 0; s < KMAX; ++s) {
             if (s < L.nkc) {
 #pragma unroll
                 for (int c = 0; c < CTC; ++c) {
-#ifdef ZLY_HEAD_DIAG
-                    if (a.diag & 1) { accc[c] = hmma(xc[(s + c) % KMAX], xc[s], accc[c]); continue; }      // diagnostic: no weight loads
-#endif
                     const F wf = *reinterpret_cast<const F*>(w + ((size_t)c * L.nkc + s) * WTILE);
                     accc[c] = hmma(wf, xc[s], accc[c]);
                 }
             }
         }
     }
-    // Early out (production: no head tensor, no logit dump): when NO anchor of the tile has a class logit above skip_logit =
-    // logit(conf_thr) - 1e-2, none can reach the confidence threshold (the margin is four orders of magnitude above the error of
-    // v_exp / v_rcp), and the box GEMM, the DFL and the 80 sigmoids per anchor are skipped -- ~4 of 5 tiles on a detector that passes
-    // ~1.5 % of its anchors.  Tiles that are not skipped run the full arithmetic below, so the candidates are exactly the same.
-#ifdef ZLY_HEAD_DIAG
-    if (a.diag & 4) { if (accc[0][0] == 123.456f && a.cand_count) a.cand_count[f] = 1; return; }         // diagnostic: stop after the class GEMM
-#endif
     if (a.head == nullptr && L.logits == nullptr) {
         float zmax = -3.0e38f;
 #pragma unroll
@@ -131,7 +139,15 @@ __global__ __launch_bounds__(256) void head_fused_kernel(const HeadArgs a)
 #pragma unroll
     for (int c = 0; c < 4; ++c) accb[c] = f32x4{0.f, 0.f, 0.f, 0.f};
     {
-        const T* w = static_cast<const T*>(L.wb) + lane * EPL;
+        F xb[KMAX];
+        const T* pb = static_cast<const T*>(L.box_in) + pix * L.box_cs;
+#pragma unroll
+        for (int s = 0; s < KMAX; ++s) {
+            const int ci = s * KSTEP + kq * EPL;
+            xb[s] = zero;
+            if (s < L.nkb && valid && ci < L.box_cin) xb[s] = *reinterpret_cast<const F*>(pb + ci);
+        }
+        const T* w = lwb + lane * EPL;
 #pragma unroll
         for (int s = 0; s < KMAX; ++s) {
             if (s < L.nkb) {
@@ -260,8 +276,11 @@ hipError_t launch_head_fused(int dtype, const HeadArgs& a0, int n, hipStream_t s
     head_fn fn = dtype == ZLY_DTYPE_BF16 ? pick_head<bf16_t>(ctc) : pick_head<float>(ctc);
     if (!fn) return hipErrorInvalidValue;                  // nc > 80 is not supported by this kernel
     if (a.only_level > 2) return hipErrorInvalidValue;
-    const int blocks = a.only_level >= 0 ? (a.lv[a.only_level].hw + 63) / 64 : a.total_blocks;
-    hipLaunchKernelGGL(fn, dim3(blocks, n), dim3(256), 0, s, a);
+    size_t lds = 0;
+    for (int l = 0; l < 3; ++l) { const size_t b = (size_t)(4 * a.lv[l].nkb + ctc * a.lv[l].nkc) * 1024; lds = b > lds ? b : lds; }
+    if (lds > 64 * 1024) return hipErrorInvalidValue;
+    const int blocks = a.only_level >= 0 ? (a.lv[a.only_level].hw + HEAD_GROUP - 1) / HEAD_GROUP : a.total_blocks;
+    hipLaunchKernelGGL(fn, dim3(blocks, n), dim3(HEAD_WAVES * 64), lds, s, a);
     return hipGetLastError();
 }
 

@@ -6,6 +6,7 @@
 // calculateIoU :881-909.  FP contraction is OFF for this file so that the IoU arithmetic is the
 // same sequence of IEEE fp32 operations as the CPU oracle (oracle/zly_oracle.c).
 #include "zly_internal.h"
+#include <stdlib.h>
 
 #pragma clang fp contract(off)
 
@@ -184,9 +185,107 @@ __device__ void nms_general(const Cand* gsrc, int n, float iou_thr, int nc, Cand
     if (tid == 0) *n_kept_out = *run_base;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fast path: a frame with at most NMS_WAVE_CAP candidates is handled by ONE wave, in registers -- the common case of a detector at
+// conf 0.5 (the synthetic model: median 55 per frame, a trained one fewer).  The eight-wave path below spends its time in workgroup
+// barriers, LDS atomics and ~27 ds_bpermute round trips per class for a few dozen boxes.  Here:
+//   lane l holds candidates l and l + 64 (arrival order); its rank under the reference's sort key -- class asc, confidence desc
+//   (:846-851), anchor asc for exact ties -- is counted against every candidate with v_readlane broadcasts (wave-uniform index: no
+//   LDS crossbar); the sorted list is materialised through 4 KB of LDS; then the reference's greedy loop (:856-875) runs over the
+//   sorted positions that are alive AND have a same-class successor (anything else cannot suppress), every lane testing its two
+//   candidates against the broadcast box, one __ballot per half clearing the suppressed ones (same class, IoU > thr strictly, :866-871).
+// Output order = sorted order of the survivors = the reference's.  Same IEEE op sequence for the IoU as the general path.
+// Measured in the engine (batch 64, median 55 candidates): 46 -> 31 us; batch 1: 14 -> 10.5 us.
+// ------------------------------------------------------------------------------------------------
+#define NMS_WAVE_CAP 128
+
+__device__ __forceinline__ float rl_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ int rl_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+
+__device__ __forceinline__ void nms_wave(const Cand* __restrict__ gsrc, int n, float iou_thr, Cand* lds, zly_det* dets, int cap, int* n_kept_out)
+{
+    const int lane = threadIdx.x & 63;
+    const bool two = n > 64;
+    const int nA = two ? 64 : n, nB = two ? n - 64 : 0;
+    Cand a, b;
+    a.x = a.y = a.w = a.h = 0.f; a.conf = 0.f; a.cls = 0x7fffffff; a.anchor = 0x7fffffff; a.pad_ = 0;
+    b = a;
+    if (lane < nA) a = gsrc[lane];
+    if (lane < nB) b = gsrc[lane + 64];
+    // sort key: (class asc, confidence desc) -- confidences are positive floats, whose bit patterns order like the values -- then the anchor index
+    const unsigned ahi = (unsigned)a.cls, alo = ~(unsigned)__float_as_int(a.conf);
+    const unsigned bhi = (unsigned)b.cls, blo = ~(unsigned)__float_as_int(b.conf);
+    auto before = [](unsigned ohi, unsigned olo, int oan, unsigned hi, unsigned lo, int an) {
+        return ohi < hi || (ohi == hi && (olo < lo || (olo == lo && oan < an)));
+    };
+    int ra = 0, rb = 0;
+    for (int k = 0; k < nA; ++k) {
+        const unsigned ohi = (unsigned)rl_i((int)ahi, k), olo = (unsigned)rl_i((int)alo, k);
+        const int oan = rl_i(a.anchor, k);
+        ra += before(ohi, olo, oan, ahi, alo, a.anchor) ? 1 : 0;
+        rb += before(ohi, olo, oan, bhi, blo, b.anchor) ? 1 : 0;
+    }
+    for (int k = 0; k < nB; ++k) {
+        const unsigned ohi = (unsigned)rl_i((int)bhi, k), olo = (unsigned)rl_i((int)blo, k);
+        const int oan = rl_i(b.anchor, k);
+        ra += before(ohi, olo, oan, ahi, alo, a.anchor) ? 1 : 0;
+        rb += before(ohi, olo, oan, bhi, blo, b.anchor) ? 1 : 0;
+    }
+    if (lane < nA) lds[ra] = a;
+    if (lane < nB) lds[rb] = b;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // sorted position p: A = lane, B = lane + 64; successor of the same class?
+    int nxa = 0x7ffffffe, nxb = 0x7ffffffe;
+    if (lane < nA) a = lds[lane];
+    if (lane < nB) b = lds[lane + 64];
+    if (lane + 1 < n) nxa = lds[lane + 1].cls;
+    if (lane + 65 < n) nxb = lds[lane + 65].cls;
+    unsigned long long aliveA = nA >= 64 ? ~0ull : ((1ull << nA) - 1ull);
+    unsigned long long aliveB = nB >= 64 ? ~0ull : ((1ull << nB) - 1ull);
+    unsigned long long todoA = __ballot(lane < nA && nxa == a.cls);
+    unsigned long long todoB = __ballot(lane < nB && nxb == b.cls);
+    while (todoA) {
+        const int i = __builtin_ctzll(todoA);
+        todoA &= todoA - 1ull;
+        if (!((aliveA >> i) & 1ull)) continue;               // wave-uniform
+        Cand bi;
+        bi.x = rl_f(a.x, i); bi.y = rl_f(a.y, i); bi.w = rl_f(a.w, i); bi.h = rl_f(a.h, i);
+        const int ci = rl_i(a.cls, i);
+        const bool killA = lane > i && a.cls == ci && iou_cxcywh(bi, a) > iou_thr;
+        aliveA &= ~__ballot(killA);
+        if (two) {
+            const bool killB = b.cls == ci && iou_cxcywh(bi, b) > iou_thr;
+            aliveB &= ~__ballot(killB);
+        }
+    }
+    while (todoB) {
+        const int i = __builtin_ctzll(todoB);
+        todoB &= todoB - 1ull;
+        if (!((aliveB >> i) & 1ull)) continue;
+        Cand bi;
+        bi.x = rl_f(b.x, i); bi.y = rl_f(b.y, i); bi.w = rl_f(b.w, i); bi.h = rl_f(b.h, i);
+        const int ci = rl_i(b.cls, i);
+        const bool killB = lane > i && b.cls == ci && iou_cxcywh(bi, b) > iou_thr;
+        aliveB &= ~__ballot(killB);
+    }
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const int keptA = __popcll(aliveA);
+    if ((aliveA >> lane) & 1ull) {
+        const int o = __popcll(aliveA & below);
+        if (o < cap) write_det(&dets[o], a);
+    }
+    if ((aliveB >> lane) & 1ull) {
+        const int o = keptA + __popcll(aliveB & below);
+        if (o < cap) write_det(&dets[o], b);
+    }
+    if (lane == 0) *n_kept_out = keptA + __popcll(aliveB);
+}
+
 __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const Cand* __restrict__ cand_all, int* __restrict__ cand_count,
                                                           int N, float iou_thr, int nc, Cand* __restrict__ scratch_all,
-                                                          unsigned char* __restrict__ slabs, int cap, uint32_t tag0)
+                                                          unsigned char* __restrict__ slabs, int cap, uint32_t tag0, int force_general)
 {
     __shared__ Cand lds_c[NMS_LDS_CAP];           // class-bucketed candidates (general path: sorted list)
     __shared__ int cls_cnt[NMS_MAX_CLASSES];      // candidates per class -> later: kept per class
@@ -204,6 +303,17 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const Cand* __restrict
     zly_slab_header* hdr = reinterpret_cast<zly_slab_header*>(slabs + (size_t)f * slab_bytes);
     zly_det* dets = reinterpret_cast<zly_det*>(hdr + 1);
 
+    if (n <= NMS_WAVE_CAP && !force_general) {         // the common case: one wave, registers (nms_wave above); uniform per workgroup
+        if (wave != 0) return;
+        if (lane == 0) cand_count[f] = 0;              // self-cleaning: the next frame's decode appends from 0 again (no memset launch)
+        int kept = 0;
+        nms_wave(gsrc, n, iou_thr, lds_c, dets, cap, &kept);
+        if (lane == 0) {
+            hdr->n_kept = kept; hdr->n_candidates = n;
+            hdr->flags = kept > cap ? ZLY_SLAB_OVERFLOW : 0u; hdr->frame_tag = tag0 + (uint32_t)f;
+        }
+        return;
+    }
     for (int c = tid; c < nc; c += NMS_THREADS) { cls_cnt[c] = 0; cls_fill[c] = 0; }
     if (tid == 0) { sh_misc[0] = 0; sh_misc[2] = 0; }
     __syncthreads();
@@ -334,8 +444,9 @@ hipError_t launch_nms(const Cand* cand, int* cand_count, int N, int n, float iou
                       Cand* scratch, void* slabs, int cap, uint32_t tag0, hipStream_t s)
 {
     if (nc > NMS_MAX_CLASSES) return hipErrorInvalidValue;
+    static const int force_general = getenv("ZLY_NMS_GENERAL") != nullptr ? 1 : 0;     // tests / A-B: every frame on the eight-wave path
     hipLaunchKernelGGL(nms_kernel, dim3(n), dim3(NMS_THREADS), 0, s, cand, cand_count, N, iou_thr, nc, scratch,
-                       (unsigned char*)slabs, cap, tag0);
+                       (unsigned char*)slabs, cap, tag0, force_general);
     return hipGetLastError();
 }
 

@@ -183,41 +183,106 @@ __global__ __launch_bounds__(NW * 64) void stem_model1_kernel(const Stem1Args a)
     const bool same = d.w == a.st.tw && d.h == a.st.th;
     const size_t frame_bytes = (size_t)d.w * d.h * 3;
     const float invPW = 1.0f / (float)PW, invRW = 1.0f / (float)RW, invTW = 1.0f / (float)a.TW;
-    // all of a thread's loads are issued before the first conversion (the loop below is fully unrolled: STEM1_MAXIT pixels per thread):
-    // with one load per loop iteration every iteration exposed a full memory round trip, ~6 us of the ~12 us a tile took
-    unsigned int raw[STEM1_MAXIT];
+    if (same) {
+        // Request size == model size (the metric's configuration): the resize map is the identity and a patch row is PW * 3 contiguous
+        // bytes of the frame.  A thread takes FOUR consecutive pixels: one 12-byte load, v_cvt_f32_ubyte0..3 straight off the dwords, 12
+        // multiplies, packed converts, two 16-byte LDS stores -- ~9 VALU per pixel.  (The general path below spends ~40 per pixel on the
+        // per-pixel index map, bounds tests, 64-bit addressing and byte shuffles; this kernel is VALU-issue bound.)  Quads that touch the
+        // frame border (or the patch's last, partial quad) take the per-pixel path.
+        const int QW = (PW + 3) >> 2;                            // quads per patch row
+        const float invQW = 1.0f / (float)QW;
+        for (int u0 = 0; u0 < PH * QW; u0 += NW * 64 * 2) {
+            unsigned int r0[2][3];
+            int mode[2], pyq[2], pxq[2];
 #pragma unroll
-    for (int k = 0; k < STEM1_MAXIT; ++k) {
-        const int u = tid + k * NW * 64;
-        raw[k] = 0x80000000u;                                   // bit 31: pixel outside the model-sized image (or beyond the patch) -> zeros
-        if (u < PH * PW) {
-            const int py = div_small_s(u, invPW), px = u - py * PW;
-            const int iy = iy0 + py, ix = ix0 + px;
-            if ((unsigned)iy < (unsigned)a.st.th && (unsigned)ix < (unsigned)a.st.tw) {
-                int sy = iy, sx = ix;
-                if (!same) {
-                    sy = (int)((float)iy * scale_h); if (sy > d.h - 1) sy = d.h - 1;
-                    sx = (int)((float)ix * scale_w); if (sx > d.w - 1) sx = d.w - 1;
+            for (int k = 0; k < 2; ++k) {
+                const int u = u0 + k * NW * 64 + tid;
+                mode[k] = 0;                                     // 0: nothing to do, 1: fast quad, 2: per-pixel quad
+                if (u < PH * QW) {
+                    const int py = div_small_s(u, invQW), q4 = (u - py * QW) * 4;
+                    pyq[k] = py; pxq[k] = q4;
+                    const int iy = iy0 + py, ix = ix0 + q4;
+                    const bool row_in = (unsigned)iy < (unsigned)a.st.th;
+                    const bool fast = row_in && ix >= 0 && ix + 3 < a.st.tw && q4 + 3 < PW && ((size_t)iy * d.w + ix) * 3 + 12 <= frame_bytes;
+                    mode[k] = fast ? 1 : 2;
+                    if (fast) {
+                        const uint8_t* q = src + ((size_t)iy * d.w + ix) * 3;
+                        typedef unsigned int u32x3 __attribute__((ext_vector_type(3), aligned(1)));
+                        const u32x3 v = *reinterpret_cast<const u32x3*>(q);          // 12 bytes: B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3 (unaligned global access is enabled on amdhsa)
+                        r0[k][0] = v[0]; r0[k][1] = v[1]; r0[k][2] = v[2];
+                    }
                 }
-                const size_t off = ((size_t)sy * d.w + sx) * 3;
-                const uint8_t* q = src + off;
-                unsigned int px4;
-                if (off + 4 <= frame_bytes) __builtin_memcpy(&px4, q, 4);        // B | G<<8 | R<<16 | next B<<24 (unaligned global access is enabled on amdhsa)
-                else px4 = (unsigned int)q[0] | ((unsigned int)q[1] << 8) | ((unsigned int)q[2] << 16);
-                raw[k] = px4 & 0x00ffffffu;
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                if (mode[k] == 1) {
+                    const float kk = 1.0f / 255.0f;              // bf16(u8 * (1/255.f)) == bf16(u8 / 255.f) for all 256 values (tests/test_model_spec.py)
+                    const unsigned int w0 = r0[k][0], w1 = r0[k][1], w2 = r0[k][2];
+                    const float b0 = (float)(w0 & 0xffu) * kk, g0 = (float)((w0 >> 8) & 0xffu) * kk, rr0 = (float)((w0 >> 16) & 0xffu) * kk;
+                    const float b1 = (float)(w0 >> 24) * kk, g1 = (float)(w1 & 0xffu) * kk, rr1 = (float)((w1 >> 8) & 0xffu) * kk;
+                    const float b2 = (float)((w1 >> 16) & 0xffu) * kk, g2 = (float)(w1 >> 24) * kk, rr2 = (float)(w2 & 0xffu) * kk;
+                    const float b3 = (float)((w2 >> 8) & 0xffu) * kk, g3 = (float)((w2 >> 16) & 0xffu) * kk, rr3 = (float)(w2 >> 24) * kk;
+                    bf16x8 lo, hi;
+                    lo[0] = (bf16_t)rr0; lo[1] = (bf16_t)g0; lo[2] = (bf16_t)b0; lo[3] = (bf16_t)0.f; lo[4] = (bf16_t)rr1; lo[5] = (bf16_t)g1; lo[6] = (bf16_t)b1; lo[7] = (bf16_t)0.f;
+                    hi[0] = (bf16_t)rr2; hi[1] = (bf16_t)g2; hi[2] = (bf16_t)b2; hi[3] = (bf16_t)0.f; hi[4] = (bf16_t)rr3; hi[5] = (bf16_t)g3; hi[6] = (bf16_t)b3; hi[7] = (bf16_t)0.f;
+                    bf16x4* dst = patch + pyq[k] * PW + pxq[k];      // 8 bytes per pixel: pairs are 16-byte stores only when aligned -- use four-pixel-safe 8-byte pairs
+                    reinterpret_cast<bf16x4*>(dst)[0] = bf16x4{lo[0], lo[1], lo[2], lo[3]};
+                    reinterpret_cast<bf16x4*>(dst)[1] = bf16x4{lo[4], lo[5], lo[6], lo[7]};
+                    reinterpret_cast<bf16x4*>(dst)[2] = bf16x4{hi[0], hi[1], hi[2], hi[3]};
+                    reinterpret_cast<bf16x4*>(dst)[3] = bf16x4{hi[4], hi[5], hi[6], hi[7]};
+                } else if (mode[k] == 2) {
+                    for (int j = 0; j < 4; ++j) {
+                        const int pxx = pxq[k] + j;
+                        if (pxx >= PW) break;
+                        const int iy = iy0 + pyq[k], ix = ix0 + pxx;
+                        bf16x4 v = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+                        if ((unsigned)iy < (unsigned)a.st.th && (unsigned)ix < (unsigned)a.st.tw) {
+                            const uint8_t* q = src + ((size_t)iy * d.w + ix) * 3;
+                            const float kk = 1.0f / 255.0f;
+                            v[0] = (bf16_t)((float)q[2] * kk); v[1] = (bf16_t)((float)q[1] * kk); v[2] = (bf16_t)((float)q[0] * kk);
+                        }
+                        patch[pyq[k] * PW + pxx] = v;
+                    }
+                }
             }
         }
-    }
-#pragma unroll
-    for (int k = 0; k < STEM1_MAXIT; ++k) {
-        const int u = tid + k * NW * 64;
-        if (u < PH * PW) {
-            bf16x4 v = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
-            if (!(raw[k] & 0x80000000u)) {
-                const float kk = 1.0f / 255.0f;                  // bf16(u8 * (1/255.f)) == bf16(u8 / 255.f) for all 256 values (tests/test_model_spec.py)
-                v[0] = (bf16_t)((float)((raw[k] >> 16) & 0xffu) * kk); v[1] = (bf16_t)((float)((raw[k] >> 8) & 0xffu) * kk); v[2] = (bf16_t)((float)(raw[k] & 0xffu) * kk);
+    } else {
+        // all of a thread's loads are issued before the first conversion (the loop below is fully unrolled: STEM1_MAXIT pixels per thread):
+        // with one load per loop iteration every iteration exposed a full memory round trip, ~6 us of the ~12 us a tile took
+        unsigned int raw[STEM1_MAXIT];
+    #pragma unroll
+        for (int k = 0; k < STEM1_MAXIT; ++k) {
+            const int u = tid + k * NW * 64;
+            raw[k] = 0x80000000u;                                   // bit 31: pixel outside the model-sized image (or beyond the patch) -> zeros
+            if (u < PH * PW) {
+                const int py = div_small_s(u, invPW), px = u - py * PW;
+                const int iy = iy0 + py, ix = ix0 + px;
+                if ((unsigned)iy < (unsigned)a.st.th && (unsigned)ix < (unsigned)a.st.tw) {
+                    int sy = iy, sx = ix;
+                    if (!same) {
+                        sy = (int)((float)iy * scale_h); if (sy > d.h - 1) sy = d.h - 1;
+                        sx = (int)((float)ix * scale_w); if (sx > d.w - 1) sx = d.w - 1;
+                    }
+                    const size_t off = ((size_t)sy * d.w + sx) * 3;
+                    const uint8_t* q = src + off;
+                    unsigned int px4;
+                    if (off + 4 <= frame_bytes) __builtin_memcpy(&px4, q, 4);        // B | G<<8 | R<<16 | next B<<24 (unaligned global access is enabled on amdhsa)
+                    else px4 = (unsigned int)q[0] | ((unsigned int)q[1] << 8) | ((unsigned int)q[2] << 16);
+                    raw[k] = px4 & 0x00ffffffu;
+                }
             }
-            patch[u] = v;
+        }
+    #pragma unroll
+        for (int k = 0; k < STEM1_MAXIT; ++k) {
+            const int u = tid + k * NW * 64;
+            if (u < PH * PW) {
+                bf16x4 v = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+                if (!(raw[k] & 0x80000000u)) {
+                    const float kk = 1.0f / 255.0f;                  // bf16(u8 * (1/255.f)) == bf16(u8 / 255.f) for all 256 values (tests/test_model_spec.py)
+                    v[0] = (bf16_t)((float)((raw[k] >> 16) & 0xffu) * kk); v[1] = (bf16_t)((float)((raw[k] >> 8) & 0xffu) * kk); v[2] = (bf16_t)((float)(raw[k] & 0xffu) * kk);
+                }
+                patch[u] = v;
+            }
         }
     }
     __syncthreads();

@@ -130,6 +130,8 @@ struct HeadLevel {
     int H, W, hw, stride_px, anchor_off, block0;
     float* logits; int logits_cs;             // optional fp32 [n][H*W][logits_cs] dump (debug taps), or null
 };
+#define HEAD_WAVES 8                          // waves per workgroup of the fused Detect tail, one 16-anchor tile each
+#define HEAD_GROUP (HEAD_WAVES * 16)          // anchors per workgroup; HeadLevel::block0 / total_blocks count these groups
 struct HeadArgs {
     HeadLevel lv[3];
     int nc, N_total, total_blocks;

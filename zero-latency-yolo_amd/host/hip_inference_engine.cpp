@@ -386,15 +386,17 @@ std::unordered_map<std::string, std::string> HipInferenceEngine::getStatus() con
         std::lock_guard<std::mutex> lk(engines_mutex_);
         engines = engines_;
     }
-    uint64_t frames = 0, batches = 0;
+    uint64_t frames = 0, batches = 0, replays = 0, eager = 0;
     double pre = 0, fwd = 0, post = 0;
     for (const auto& h : engines) {
         zly_stats st{};
         if (zly_get_stats(h->e, &st) != ZLY_OK) continue;
-        frames += st.sampled_frames; batches += st.batches;
+        frames += st.sampled_frames; batches += st.batches; replays += st.graph_replays; eager += st.eager_batches;
         pre += st.sampled_preprocess_ms; fwd += st.sampled_forward_ms; post += st.sampled_postprocess_ms;
     }
     s["batches"] = std::to_string(batches);
+    s["graph_replays"] = std::to_string(replays);          // batches whose forward was one hipGraph replay (lone frames and full batches) ...
+    s["eager_batches"] = std::to_string(eager);            // ... or kernel-by-kernel launches (partial batches)
     s["avg_preprocessing_time_ms"] = frames ? std::to_string(pre / (double)frames) : "0";
     s["avg_forward_time_ms"] = frames ? std::to_string(fwd / (double)frames) : "0";
     s["avg_postprocessing_time_ms"] = frames ? std::to_string(post / (double)frames) : "0";

@@ -1,4 +1,5 @@
-// head_bench.hip -- DIAGNOSTIC: what binds head_fused_kernel?  Runs the Detect tail of a YOLOv8n 416x416 batch (3549 anchors x n frames,
+// head_bench.hip -- stand-alone timing of head_fused_kernel (the ablation of its predecessor is in profiles/r03_head_kernel_ablation.txt).
+// Originally: DIAGNOSTIC: what binds head_fused_kernel?  Runs the Detect tail of a YOLOv8n 416x416 batch (3549 anchors x n frames,
 // random bf16 activations, class logits ~N(-2.75, 0.7) so that ~1.5 % of the anchors pass conf 0.5) with parts switched off:
 //   bit 0: no weight-fragment loads (L1 / L2 traffic), bit 1: no activation loads (HBM), bit 2: stop after the class GEMM (no epilogue).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Izero-latency-yolo_amd/csrc -DZLY_HEAD_DIAG=1 zero-latency-yolo_amd/tools/head_bench.hip \
@@ -37,7 +38,7 @@ int main(int argc, char** argv)
         L.box_in = dhb; L.cls_in = dhc; L.box_cs = 64; L.cls_cs = 80; L.box_cin = 64; L.cls_cin = 80;
         L.wb = dwb; L.wc = dwc; L.bb = dbb; L.bc = dbc; L.nkb = 2; L.nkc = 3;
         L.H = Ws[l]; L.W = Ws[l]; L.hw = hw[l]; L.stride_px = 8 << l; L.anchor_off = off; L.block0 = block0; L.logits = nullptr; L.logits_cs = 144;
-        block0 += (hw[l] + 63) / 64; off += hw[l];
+        block0 += (hw[l] + HEAD_GROUP - 1) / HEAD_GROUP; off += hw[l];
     }
     a.nc = 80; a.N_total = off; a.total_blocks = block0; a.only_level = -1; a.head = nullptr; a.conf_thr = 0.5f;
     FrameDesc* dd; std::vector<FrameDesc> hd((size_t)n); for (auto& d : hd) { d.src_off = 0; d.w = 416; d.h = 416; }
@@ -48,7 +49,7 @@ int main(int argc, char** argv)
     const char* names[8] = {"full kernel", "no weight loads", "no activation loads", "no weight + no activation loads", "stop after class GEMM",
                             "stop after class GEMM, no weight loads", "stop after class GEMM, no activation loads", "stop after class GEMM, no loads at all"};
     for (int round = 0; round < 2; ++round)                          // round 0 warms the clocks up
-        for (int mode = 0; mode < 8; ++mode) {
+        for (int mode = 0; mode < 1; ++mode) {       // the ablation switches (modes 1-7: profiles/r03_head_kernel_ablation.txt) lived in the one-tile-per-workgroup-wave kernel of round 2
             a.diag = mode;
             float best = 1e9f, ms = 0;
             for (int rep = 0; rep < 30; ++rep) {

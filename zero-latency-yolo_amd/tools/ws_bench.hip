@@ -24,9 +24,9 @@ static void run(const char* name, int n, int H, int W, int Cin, int Cout)
     a.out = dout; a.out_cs = Cout; a.Ho = H; a.Wo = W; a.Cout = Cout; a.cout_pad = cout_pad; a.stride = 1; a.pad = 1;
     a.K = 9 * Cin; a.nk = nk; a.M = n * H * W; a.act = 1;
     WsGeom g{};
-    if (!ws_plan(H, W, Cin, &g)) { printf("%s: no plan\n", name); return; }
+    if (!ws_plan(H, W, Cin, n, &g)) { printf("%s: no plan\n", name); return; }
     g.total_tiles = g.tiles_x * g.tiles_y * n;
-    const size_t lds = ((size_t)(g.TH + 2) * (g.TW + 2) * g.pitch + 15) / 16 * 16;
+    const size_t lds = ((size_t)(g.TH + 2) * (g.TW + 8) * g.pitch + 1023) / 1024 * 1024;
     const int gx = g.total_tiles < 512 ? g.total_tiles : 512;
     const size_t nw = (size_t)gx * 4;
     hipMalloc((void**)&ddbg, nw * 64); hipMemset(ddbg, 0, nw * 64);
@@ -48,7 +48,7 @@ static void run(const char* name, int n, int H, int W, int Cin, int Cout)
     const double tpw = (double)g.total_tiles / gx;
     const double gflop = 2.0 * n * H * W * (double)Cout * 9 * Cin / 1e9;
     const int nct = (g.TH * g.TW + 15) / 16, nwc = (ntiles > even ? 1 : even / 2), nwp = 4 / nwc, tiles_w = ntiles > even ? 1 : 2;
-    printf("%-30s tile %dx%d (%d column tiles) lds=%zuKB grid %d%s: %.1f us best of 20 (%.0f TFLOP/s)  last launch, cycles/tile/wave: barrier %.0f  patch %.0f  loop %.0f | wave total %.0f per tile (bare MFMA %d)\n",
+    printf("%-30s tile %dx%d (%d column tiles) lds=%zuKB grid %d%s: %.1f us best of 20 (%.0f TFLOP/s)  last launch, cycles/tile/wave: patch wait + barrier %.0f  barrier + next-patch dma issue %.0f  loop %.0f | wave total %.0f per tile (bare MFMA %d)\n",
            name, g.TH, g.TW, nct, lds / 1024, gx, ntiles > even ? " + odd-tile launch" : "", best * 1e3, gflop / (best * 1e-3) / 1e3,
            s[0] / nw / tpw, s[1] / nw / tpw, s[2] / nw / tpw, s[3] / nw / tpw, (nct + nwp - 1) / nwp * tiles_w * nk * 16);
     hipFree(din); hipFree(dw); hipFree(dout); hipFree(dbias); hipFree(ddbg);

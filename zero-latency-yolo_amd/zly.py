@@ -58,7 +58,7 @@ class Stats(C.Structure):
                 ("total_preprocess_ms", C.c_double), ("total_forward_ms", C.c_double),
                 ("total_postprocess_ms", C.c_double), ("last_detect_ms", C.c_double),
                 ("sampled_frames", C.c_uint64), ("sampled_preprocess_ms", C.c_double), ("sampled_forward_ms", C.c_double),
-                ("sampled_postprocess_ms", C.c_double), ("batches", C.c_uint64)]
+                ("sampled_postprocess_ms", C.c_double), ("batches", C.c_uint64), ("graph_replays", C.c_uint64), ("eager_batches", C.c_uint64)]
 
 
 class OpInfo(C.Structure):
