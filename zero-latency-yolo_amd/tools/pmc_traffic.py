@@ -10,7 +10,7 @@ import json
 import os
 import sys
 
-CONV = ("conv_igemm_kernel", "conv3x3_lds_kernel", "stem_fused_kernel", "stem_model1_kernel", "conv1x1_stream_kernel", "bottleneck_pair_kernel", "c2f_kernel")
+CONV = ("conv_igemm_kernel", "conv3x3_lds_kernel", "conv3x3_ws_kernel", "stem_fused_kernel", "stem_model1_kernel", "conv1x1_stream_kernel", "bottleneck_pair_kernel", "c2f_kernel")
 
 
 def collect(d, counter):
@@ -47,7 +47,7 @@ def main():
     read_b, write_b = 2.0 * fr * 1024 / sr, wr * 1024 / sw
     j = {
         "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (two separate passes), python3 bench.py --batch 64 --steps 6 --warmup 1 --no-extras; "
-                  "MFMA conv family (conv_igemm + conv3x3_lds + conv1x1_stream + bottleneck_pair + c2f + stem_model1) summed over one batch-64 step, mean over the profiled steps",
+                  "MFMA conv family (conv_igemm + conv3x3_lds + conv3x3_ws + conv1x1_stream + bottleneck_pair + c2f + stem_model1) summed over one batch-64 step, mean over the profiled steps",
         "correction": "gfx950: FETCH_SIZE doubled (MI355X_MICROARCH.md, HBM section); WRITE_SIZE as read; both counters include Infinity-Cache hits",
         "steps_profiled": [sr, sw],
         "fetch_size_kb_per_step": fr / sr, "write_size_kb_per_step": wr / sw,

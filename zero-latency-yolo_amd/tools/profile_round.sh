@@ -3,15 +3,15 @@
 #   kernel trace + stats of ONE engine's chain (--engines 1: per-position table, one-step timeline), kernel stats of the default
 #   three-engine headline, PMC traffic (two passes, one engine)
 set -e
-tag=${1:-r02}
+tag=${1:-r03}
 out=gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 export ZLY_BENCH_NO_H2H=1
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt3 -- python3 bench.py --batch 64 --steps 40 --warmup 5 --no-extras --no-cpu-baseline > $out/kt3_bench.json 2> $out/kt3.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt3 -- python3 bench.py --batch 64 --steps 40 --warmup 5 --blocks 2 --no-extras --no-cpu-baseline > $out/kt3_bench.json 2> $out/kt3.err
 cp "$(find $out/kt3 -name '*kernel_stats.csv' | head -1)" $out/kernel_stats_3engines.csv
 rm -rf $out/kt3
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -- python3 bench.py --batch 64 --steps 40 --warmup 5 --no-extras --no-cpu-baseline --engines 1 > $out/kt_bench.json 2> $out/kt.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -- python3 bench.py --batch 64 --steps 40 --warmup 5 --blocks 2 --no-extras --no-cpu-baseline --engines 1 > $out/kt_bench.json 2> $out/kt.err
 kt=$(find $out/kt -name "*kernel_trace.csv" | head -1)
 st=$(find $out/kt -name "*kernel_stats.csv" | head -1)
 cp "$st" $out/kernel_stats.csv
@@ -25,8 +25,8 @@ PY
 )
 python3 zero-latency-yolo_amd/tools/trace_summary.py "$kt" $n $out/per_position.txt
 python3 zero-latency-yolo_amd/tools/trace_timeline.py "$kt" 3 > $out/timeline.txt
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_r -- python3 bench.py --batch 64 --steps 6 --warmup 1 --no-extras --no-cpu-baseline --engines 1 > /dev/null 2> $out/pmc_r.err
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_w -- python3 bench.py --batch 64 --steps 6 --warmup 1 --no-extras --no-cpu-baseline --engines 1 > /dev/null 2> $out/pmc_w.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_r -- python3 bench.py --batch 64 --steps 6 --warmup 1 --blocks 1 --no-extras --no-cpu-baseline --engines 1 > /dev/null 2> $out/pmc_r.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_w -- python3 bench.py --batch 64 --steps 6 --warmup 1 --blocks 1 --no-extras --no-cpu-baseline --engines 1 > /dev/null 2> $out/pmc_w.err
 python3 zero-latency-yolo_amd/tools/pmc_traffic.py $out/pmc_r $out/pmc_w $out/traffic_b64.json
 rm -rf $out/pmc_r $out/pmc_w $out/kt
 echo "profile set in $out"
