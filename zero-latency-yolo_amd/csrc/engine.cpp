@@ -74,7 +74,7 @@ struct Op {
     // fused C2f block (kernels_pair.hip: c2f_kernel): c2f_mode != 0 on the op that launches it (cv1, or the second bottleneck's first
     // conv for the back half of a two-bottleneck C2f); the ops it covers carry the leader's name and launch nothing when it is active
     int c2f_mode = 0, c2f_c = 0, c2f_res = 0, c2f_cat = -1, c2f_in_co = 0, c2f_out_co = 0, c2f_nk1 = 0, c2f_nk2 = 0, c2f_cout2 = 0;
-    View c2f_x{-1, 0, 0}, c2f_x2{-1, 0, 0}, c2f_out{-1, 0, 0};
+    View c2f_x{-1, 0, 0}, c2f_x2{-1, 0, 0}, c2f_out{-1, 0, 0}, c2f_mid{-1, 0, 0};
     size_t c2f_w1 = 0, c2f_b1 = 0, c2f_wA = 0, c2f_bA = 0, c2f_wB = 0, c2f_bB = 0, c2f_w2 = 0, c2f_b2 = 0;
     std::string c2f_leader_name;       // covered ops (and the leader itself)
     int c2f_leader = -1;               // index of the leader op (resolved after the ops are ordered)
@@ -175,7 +175,7 @@ struct zly_engine {
     std::atomic<Ingest*> ingest{nullptr};   // created by the first zly_submit (under mu), read lock-free afterwards
 
     // tuning / test switches of the environment, read ONCE at zly_create (they used to be read per launch)
-    struct Switches { bool no_c2f = false, no_det_merge = false, no_tail_split = false, no_lanes = false; } sw;
+    struct Switches { bool no_c2f = false, no_det_merge = false, no_tail_split = false, no_lanes = false; std::string ablate; } sw;
 
     std::mutex mu;                    // serialises every call that touches engine / device state
     mutable std::mutex stats_mu;      // guards `stats` only, never held across a device call: zly_get_stats cannot wait on a batch
@@ -332,12 +332,12 @@ struct PlanBuilder {
     // = cv1 + first bottleneck, back half = second bottleneck + cv2).  Weight tilings are shared with the per-conv kernels where the
     // layout is the same (C = 32); the 16-channel block gets its own cv1 (rows in channel order) and cv2 (k-steps of 16) tilings.
     bool mark_c2f(const std::string& p, int cat, int c, int n, bool shortcut, View in, View in2, View out) {
-        if (e->dtype != ZLY_DTYPE_BF16 || (c != 16 && c != 32) || (n != 1 && n != 2) || (e->cfg.flags & ZLY_FLAG_NO_FUSION)) return true;
+        if (e->dtype != ZLY_DTYPE_BF16 || (c != 16 && c != 32 && c != 64) || (n != 1 && n != 2) || (e->cfg.flags & ZLY_FLAG_NO_FUSION)) return true;
         const size_t base = e->ops.size() - (size_t)(2 + 2 * n);
         Op& cv1 = e->ops[base];
         Op& cv2 = e->ops[e->ops.size() - 1];
         const int cin = in.C + (in2.buf >= 0 ? in2.C : 0);
-        if (cin % 32 != 0 || (cv2.cout != 32 && cv2.cout != 64) || cv1.cout != 2 * c || !cv1.act || !cv2.act) return true;
+        if (cin % 32 != 0 || cv2.cout != 2 * c || cv1.cout != 2 * c || !cv1.act || !cv2.act) return true;
         for (int i = 0; i < n; ++i) if (e->ops[base + 1 + 2 * (size_t)i].pair != 1) return true;       // mark_pair declined
         size_t w1 = cv1.w_off, b1 = cv1.b_off, w2 = cv2.w_off, b2 = cv2.b_off;
         int nk1 = cv1.nk, nk2 = cv2.nk;
@@ -352,7 +352,7 @@ struct PlanBuilder {
             repack_conv({r2}, (2 + n) * c, 16, true, &w, &b, &cout, &cout_pad, &nk2, true, 4);
             w2 = append(w.data(), w.size()); b2 = append(b.data(), b.size() * sizeof(float));
         }
-        if (nk2 != 2 + n) return true;
+        if (nk2 != (c == 64 ? 2 : 1) * (2 + n)) return true;            // cv2's k-steps: one per source map (c = 16 / 32), two per map of 64 channels
         auto fill = [&](Op& L, int mode, const Op& A) {
             L.c2f_mode = mode; L.c2f_c = c; L.c2f_res = shortcut ? 1 : 0; L.c2f_cat = cat;
             L.c2f_in_co = A.in.co; L.c2f_out_co = A.pair_out.co;
@@ -360,12 +360,13 @@ struct PlanBuilder {
             L.c2f_w1 = w1; L.c2f_b1 = b1; L.c2f_nk1 = nk1; L.c2f_w2 = w2; L.c2f_b2 = b2; L.c2f_nk2 = nk2; L.c2f_cout2 = cv2.cout;
             L.c2f_wA = A.pair_wA; L.c2f_bA = A.pair_bA; L.c2f_wB = A.pair_wB; L.c2f_bB = A.pair_bB;
             L.c2f_leader_name = L.name;
+            if (c == 64) L.c2f_mid = A.out;                      // the 64-channel kernel can dump the bottleneck's intermediate map (debug taps)
         };
         if (n == 1) {
             Op& A = e->ops[base + 1];
             fill(cv1, 3, A);
             cv1.c2f_vis = 1;
-            A.c2f_leader_name = cv1.name; A.c2f_vis = 2;
+            A.c2f_leader_name = cv1.name; A.c2f_vis = c == 64 ? 1 : 2;
             e->ops[base + 2].c2f_leader_name = cv1.name; e->ops[base + 2].c2f_vis = 1;
             cv2.c2f_leader_name = cv1.name; cv2.c2f_vis = 0;
         } else {
@@ -373,10 +374,10 @@ struct PlanBuilder {
             Op& A1 = e->ops[base + 3];
             fill(cv1, 1, A0);
             cv1.c2f_vis = 0;
-            A0.c2f_leader_name = cv1.name; A0.c2f_vis = 2;
+            A0.c2f_leader_name = cv1.name; A0.c2f_vis = c == 64 ? 1 : 2;
             e->ops[base + 2].c2f_leader_name = cv1.name; e->ops[base + 2].c2f_vis = 0;
             fill(A1, 2, A1);
-            A1.c2f_vis = 2;
+            A1.c2f_vis = c == 64 ? 1 : 2;
             e->ops[base + 4].c2f_leader_name = A1.name; e->ops[base + 4].c2f_vis = 1;
             cv2.c2f_leader_name = A1.name; cv2.c2f_vis = 0;
         }
@@ -655,7 +656,7 @@ static const C2fPlan* c2f_active(zly_engine* e, const Op& L, int n)
     if (!L.c2f_mode || e->dtype != ZLY_DTYPE_BF16 || (e->cfg.flags & ZLY_FLAG_NO_FUSION)) return nullptr;
     if (e->sw.no_c2f) return nullptr;                                       // ZLY_NO_C2F: tuning / tests
     const Buffer& b = e->bufs[(size_t)L.c2f_cat];
-    const long key = ((((long)L.c2f_c * 4 + L.c2f_mode) * 4096 + n) * 4096 + b.H) * 4096 + b.W;
+    const long key = ((((((long)L.c2f_c * 4 + L.c2f_mode) * 16 + L.c2f_nk1) * 16 + L.c2f_nk2) * 4096 + n) * 4096 + b.H) * 4096 + b.W;   // nk1 / nk2: the LDS layout of the 64-channel kernel depends on them
     auto it = e->c2f_plans.find(key);
     if (it == e->c2f_plans.end()) {
         C2fPlan pl{};
@@ -839,6 +840,7 @@ static hipError_t run_op(zly_engine* e, const Op& op, int n, const uint8_t* d_sr
             ca.H = cb.H; ca.W = cb.W; ca.n = n;
             ca.TH = pl->th; ca.TW = pl->tw; ca.tiles_x = pl->tiles_x; ca.tiles_y = pl->tiles_y; ca.total_tiles = pl->total_tiles;
             ca.dump = (e->cfg.flags & ZLY_FLAG_DUMP_LOGITS) ? 1 : 0;
+            if (op.c2f_c == 64 && op.c2f_mid.buf >= 0) { const Buffer& mb = e->bufs[(size_t)op.c2f_mid.buf]; ca.mid = mb.ptr; ca.mid_cs = mb.C; }
             return launch_c2f(op.c2f_c, op.c2f_mode, ca, *pl, s);
         }
         if (op.pair) {
@@ -911,6 +913,9 @@ static hipError_t run_ops(zly_engine* e, size_t first, size_t last, int n, const
         // the side streams are joined in front of the P5 branch rather than at the very end: they have long finished by then, and
         // the hand-over (~10 us on the main stream) then overlaps nothing less than at the step boundary (+0.7 %)
         if (op.kind == OP_CONV && op.lane == 0 && op.name.rfind("model.22.cv2.2.0", 0) == 0) { join_all(); if (r != hipSuccess) break; }
+        // ZLY_ABLATE_SKIP=<op name>[,<op name>...]: the named launches are left out (results are garbage): measures what a launch costs the
+        // step when several engines' chains overlap, which its isolated duration does not tell (tools/ablate_launches.sh)
+        if (!e->sw.ablate.empty() && e->sw.ablate.find("," + op.name + ",") != std::string::npos) continue;
         r = run_op(e, op, n, d_src, d_slabs_out, tag0, st);
     }
     if (r == hipSuccess) join_all();
@@ -1601,6 +1606,7 @@ int32_t zly_create(const zly_config* cfg, zly_engine** out)
     e->dtype = cfg->dtype;
     e->esz = cfg->dtype == ZLY_DTYPE_BF16 ? 2 : 4;
     e->sw.no_c2f = getenv("ZLY_NO_C2F") != nullptr;
+    if (const char* v = getenv("ZLY_ABLATE_SKIP")) e->sw.ablate = std::string(",") + v + ",";
     e->sw.no_det_merge = getenv("ZLY_NO_DET_MERGE") != nullptr;
     e->sw.no_tail_split = getenv("ZLY_NO_TAIL_SPLIT") != nullptr;
     e->sw.no_lanes = getenv("ZLY_NO_LANES") != nullptr || getenv("ZLY_CU_PART") != nullptr;

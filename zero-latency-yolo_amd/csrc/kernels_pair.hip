@@ -269,6 +269,7 @@ __global__ __launch_bounds__(NW * 64) void bottleneck_pair_kernel(const PairArgs
 // order.  Halo pixels of cv1 are recomputed by neighbouring tiles (1.3-1.7x the cv1 work; these layers are bound by bytes
 // and SiLU issue, not by MFMAs).  With a.dump (debug taps) the intermediates are also written to the concat buffer.
 // ------------------------------------------------------------------------------------------------
+static constexpr int C2F_BIAS_BYTES = 1024;
 template <int C, int MODE, int NW, int NLD, int NK1>
 __global__ __launch_bounds__(NW * 64) void c2f_kernel(const C2fArgs a)
 {
@@ -285,7 +286,10 @@ __global__ __launch_bounds__(NW * 64) void c2f_kernel(const C2fArgs a)
     const int w1_bytes = FRONT ? T1 * a.nk1 * 1024 : 0;
     const int T2 = a.Cout2 >> 4;
     const int w2_bytes = BACK ? T2 * a.nk2 * G::WTILE : 0;
-    unsigned char* lwA = smem;
+    // biases live in LDS (1 KiB: bA | bB | b1 | b2) and are read where an epilogue needs them: as registers they were 64 VGPRs held through the
+    // whole kernel, which is what kept the 32-channel kernel from running 16 waves (128 VGPRs) without spilling
+    float* lbias = reinterpret_cast<float*>(smem);
+    unsigned char* lwA = smem + C2F_BIAS_BYTES;
     unsigned char* lwB = lwA + WBYTES;
     unsigned char* lw1 = lwB + WBYTES;
     unsigned char* lw2 = lw1 + w1_bytes;
@@ -308,23 +312,38 @@ __global__ __launch_bounds__(NW * 64) void c2f_kernel(const C2fArgs a)
     if (FRONT) stage(lw1, a.w1, w1_bytes);
     if (BACK) stage(lw2, a.w2, w2_bytes);
 
-    f32x4 biasA[G::CT], biasB[G::CT], bias1[T1], bias2[T2MAX];
-#pragma unroll
-    for (int c = 0; c < G::CT; ++c) {
-        const int ch = C == 16 ? kq * 4 : (c >> 1) * 32 + kq * 8 + (c & 1) * 4;
-        biasA[c] = *reinterpret_cast<const f32x4*>(a.bA + ch);
-        biasB[c] = *reinterpret_cast<const f32x4*>(a.bB + ch);
+    constexpr bool BIAS_LDS = C == 32 && NW == 16;     // 8-wave builds keep them in registers (an LDS read per epilogue cost them 2-4 us per launch)
+    if (BIAS_LDS) {
+        for (int u = tid; u < C; u += NT) { lbias[u] = a.bA[u]; lbias[C + u] = a.bB[u]; }
+        if (FRONT) for (int u = tid; u < 2 * C; u += NT) lbias[2 * C + u] = a.b1[u];
+        if (BACK) for (int u = tid; u < a.Cout2; u += NT) lbias[4 * C + u] = a.b2[u];
     }
+    // per-lane bias of MFMA tile c: C = 16 -> channels kq*4..+3 (cv1: c*16 + kq*4); C = 32 (pair-permuted rows) -> tiles 2j, 2j+1: j*32 + kq*8 .. +3 / +4..+7
+    constexpr int NBR = BIAS_LDS ? 1 : G::CT, NB1 = BIAS_LDS ? 1 : T1, NB2 = BIAS_LDS ? 1 : T2MAX;
+    f32x4 rbA[NBR], rbB[NBR], rb1[NB1], rb2[NB2];
+    if (!BIAS_LDS) {
 #pragma unroll
-    for (int c = 0; c < T1; ++c) {
-        // C = 16: cv1's rows are in channel order (tile 0 = y0, tile 1 = y1); C = 32: pair-permuted (tiles 0,1 = y0, tiles 2,3 = y1)
-        const int ch = C == 16 ? c * 16 + kq * 4 : (c >> 1) * 32 + kq * 8 + (c & 1) * 4;
-        bias1[c] = FRONT ? *reinterpret_cast<const f32x4*>(a.b1 + ch) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < G::CT; ++c) {
+            const int ch = C == 16 ? kq * 4 : (c >> 1) * 32 + kq * 8 + (c & 1) * 4;
+            rbA[c % NBR] = *reinterpret_cast<const f32x4*>(a.bA + ch);
+            rbB[c % NBR] = *reinterpret_cast<const f32x4*>(a.bB + ch);
+        }
+#pragma unroll
+        for (int c = 0; c < T1; ++c) {
+            const int ch = C == 16 ? c * 16 + kq * 4 : (c >> 1) * 32 + kq * 8 + (c & 1) * 4;
+            rb1[c % NB1] = FRONT ? *reinterpret_cast<const f32x4*>(a.b1 + ch) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int c = 0; c < T2MAX; ++c)
+            rb2[c % NB2] = (BACK && c < T2) ? *reinterpret_cast<const f32x4*>(a.b2 + (c >> 1) * 32 + kq * 8 + (c & 1) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-#pragma unroll
-    for (int c = 0; c < T2MAX; ++c)
-        bias2[c] = (BACK && c < T2) ? *reinterpret_cast<const f32x4*>(a.b2 + (c >> 1) * 32 + kq * 8 + (c & 1) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-
+    auto bias_of = [&](int which, int c) -> f32x4 {       // which: 0 = conv A, 1 = conv B, 2 = cv1, 3 = cv2
+        if (BIAS_LDS) {
+            const int base = which == 0 ? 0 : which == 1 ? C : which == 2 ? 2 * C : 4 * C;
+            return *reinterpret_cast<const f32x4*>(lbias + base + (c >> 1) * 32 + kq * 8 + (c & 1) * 4);
+        }
+        return which == 0 ? rbA[c % NBR] : which == 1 ? rbB[c % NBR] : which == 2 ? rb1[c % NB1] : rb2[c % NB2];
+    };
     const float invPW = 1.0f / (float)PW, invMW = 1.0f / (float)MW, invTW = 1.0f / (float)a.TW;
     const int tiles_per_img = a.tiles_x * a.tiles_y;
     const int NP0 = PH * PW, NPA = MH * MW, NPB = a.TH * a.TW;
@@ -437,7 +456,7 @@ __global__ __launch_bounds__(NW * 64) void c2f_kernel(const C2fArgs a)
                 f32x4 o[T1];
 #pragma unroll
                 for (int c = 0; c < T1; ++c) {
-                    f32x4 v = acc[c] + bias1[c];
+                    f32x4 v = acc[c] + bias_of(2, c);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = inimg ? silu<bf16_t>(v[r]) : 0.0f;      // outside the frame: the 3x3 convs' zero padding
                     o[c] = v;
@@ -471,7 +490,7 @@ __global__ __launch_bounds__(NW * 64) void c2f_kernel(const C2fArgs a)
             f32x4 o[G::CT];
 #pragma unroll
             for (int c = 0; c < G::CT; ++c) {
-                f32x4 v = acc[c] + biasA[c];
+                f32x4 v = acc[c] + bias_of(0, c);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = inimg ? silu<bf16_t>(v[r]) : 0.0f;
                 o[c] = v;
@@ -490,7 +509,7 @@ __global__ __launch_bounds__(NW * 64) void c2f_kernel(const C2fArgs a)
             f32x4 o[G::CT];
 #pragma unroll
             for (int c = 0; c < G::CT; ++c) {
-                f32x4 v = acc[c] + biasB[c];
+                f32x4 v = acc[c] + bias_of(1, c);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = silu<bf16_t>(v[r]);
                 o[c] = v;
@@ -543,7 +562,7 @@ __global__ __launch_bounds__(NW * 64) void c2f_kernel(const C2fArgs a)
 #pragma unroll
                     for (int g2 = 0; g2 < T2MAX / 2; ++g2) {
                         if (2 * g2 >= T2) break;
-                        f32x4 lo = acc[2 * g2] + bias2[2 * g2], hi = acc[2 * g2 + 1] + bias2[2 * g2 + 1];
+                        f32x4 lo = acc[2 * g2] + bias_of(3, 2 * g2), hi = acc[2 * g2 + 1] + bias_of(3, 2 * g2 + 1);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) { lo[r] = silu<bf16_t>(lo[r]); hi[r] = silu<bf16_t>(hi[r]); }
                         store8(dst + g2 * 32 + kq * 8, lo, hi);
@@ -613,10 +632,18 @@ hipError_t pair_init()
 
 // ---- fused C2f kernel -----------------------------------------------------------------------------------------------
 static constexpr int C2F_NW16 = 16, C2F_NW32 = 8, C2F_NLD = 4;
+// waves per workgroup of the 32-channel kernel: 16 (128 VGPRs, biases in LDS: four waves per SIMD hide the fragment-read and epilogue latencies
+// behind each other -- neither the vector nor the matrix pipe was half busy with two) except for the front half, which spills at 128 and keeps 8
+static int c2f_nw32(int mode)
+{
+    static const int forced = getenv("ZLY_C2F32_NW") ? atoi(getenv("ZLY_C2F32_NW")) : 0;       // tuning / tests: 8 or 16 for every mode
+    if (forced == 8 || forced == 16) return forced;
+    return mode == 1 ? C2F_NW32 : 16;          // measured at batch 64: back half 40.7 -> 30.2 us, whole block (model.15) 55.9 -> 44.9 us; the front half spills at 128 VGPRs (30.5 -> 34 us)
+}
 static size_t c2f_lds_bytes(int c, int mode, int nk1, int nk2, int cout2, int th, int tw)
 {
     const size_t pitch = (size_t)pair_pitch(c), wtile = c == 16 ? 512 : 1024, ct = c / 16;
-    size_t b = 2 * 9 * ct * wtile;
+    size_t b = C2F_BIAS_BYTES + 2 * 9 * ct * wtile;
     if (mode & 1) b += (size_t)(2 * c / 16) * nk1 * 1024;
     if (mode & 2) b += (size_t)(cout2 / 16) * nk2 * wtile;
     b += ((size_t)(th + 4) * (tw + 4) * pitch + 15) / 16 * 16 + ((size_t)(th + 2) * (tw + 2) * pitch + 15) / 16 * 16;
@@ -631,9 +658,10 @@ static c2f_fn pick_c2f(int c, int mode, int nk1);
 // tile shape: rounds of tiles over the CUs x (16-pixel tile rounds of the phases over the workgroup's waves + a fixed cost), LDS budget
 bool c2f_plan(int c, int mode, int nk1, int nk2, int cout2, int n, int H, int W, C2fPlan* plan)
 {
+    if (c == 64 && mode >= 1 && mode <= 3) return c2f64_plan(mode, nk1, nk2, cout2, n, H, W, plan);
     if ((c != 16 && c != 32) || mode < 1 || mode > 3 || !pick_c2f(c, mode, nk1)) return false;
     if ((mode & 2) && nk2 != (mode == 2 ? 4 : 3)) return false;          // concat of 3 (one bottleneck) or 4 (back half of two) sources
-    const int ncu = num_cus(), nw = c == 16 ? C2F_NW16 : C2F_NW32;
+    const int ncu = num_cus(), nw = c == 16 ? C2F_NW16 : c2f_nw32(mode);
     double best = 1e30;
     for (int th = 4; th <= 32; ++th) {
         for (int tw = 8; tw <= 64; ++tw) {
@@ -669,30 +697,33 @@ template <int C, int NW> static c2f_fn pick_c2f_c(int mode, int nk1)
     if (mode == 1) return nk1 == 1 ? c2f_kernel<C, 1, NW, C2F_NLD, 1> : nk1 == 2 ? c2f_kernel<C, 1, NW, C2F_NLD, 2> : nk1 == 6 ? c2f_kernel<C, 1, NW, C2F_NLD, 6> : nullptr;
     return nk1 == 1 ? c2f_kernel<C, 3, NW, C2F_NLD, 1> : nk1 == 2 ? c2f_kernel<C, 3, NW, C2F_NLD, 2> : nk1 == 6 ? c2f_kernel<C, 3, NW, C2F_NLD, 6> : nullptr;
 }
-static c2f_fn pick_c2f(int c, int mode, int nk1)
+static c2f_fn pick_c2f(int c, int mode, int nk1, int nw32)
 {
-    return c == 16 ? pick_c2f_c<16, C2F_NW16>(mode, nk1) : pick_c2f_c<32, C2F_NW32>(mode, nk1);
+    return c == 16 ? pick_c2f_c<16, C2F_NW16>(mode, nk1) : nw32 == 16 ? pick_c2f_c<32, 16>(mode, nk1) : pick_c2f_c<32, C2F_NW32>(mode, nk1);
 }
+static c2f_fn pick_c2f(int c, int mode, int nk1) { return pick_c2f(c, mode, nk1, c2f_nw32(mode)); }
 
 hipError_t c2f_init()
 {
     static const int nk1s[3] = {1, 2, 6};
     for (int c = 16; c <= 32; c += 16)
         for (int mode = 1; mode <= 3; ++mode)
-            for (int i = 0; i < 3; ++i) {
-                hipError_t r = hipFuncSetAttribute((const void*)pick_c2f(c, mode, nk1s[i]), hipFuncAttributeMaxDynamicSharedMemorySize, PAIR_LDS_MAX);
-                if (r != hipSuccess) return r;
-            }
-    return hipSuccess;
+            for (int i = 0; i < 3; ++i)
+                for (int nw32 = 8; nw32 <= 16; nw32 += 8) {
+                    hipError_t r = hipFuncSetAttribute((const void*)pick_c2f(c, mode, nk1s[i], nw32), hipFuncAttributeMaxDynamicSharedMemorySize, PAIR_LDS_MAX);
+                    if (r != hipSuccess) return r;
+                }
+    return c2f64_init();
 }
 
 hipError_t launch_c2f(int c, int mode, const C2fArgs& a, const C2fPlan& plan, hipStream_t s)
 {
+    if (c == 64) return launch_c2f64(mode, a, plan, s);
     if ((c != 16 && c != 32) || mode < 1 || mode > 3 || a.TH != plan.th || a.TW != plan.tw || plan.grid < 1) return hipErrorInvalidValue;
     if (a.cat_cs % 8 || a.pair_in_co % c || a.pair_out_co % c || a.out_cs % 8 || a.out_co % 8) return hipErrorInvalidValue;
     if ((mode & 1) && (a.x_cs % 8 || a.x_co % 8 || (a.x2 && (a.x2_cs % 8 || a.x2_co % 8 || a.split_c % 32 || (a.H & 1) || (a.W & 1))))) return hipErrorInvalidValue;
     if ((mode & 2) && (a.Cout2 % 32 || a.Cout2 > 64)) return hipErrorInvalidValue;
-    const int nw = c == 16 ? C2F_NW16 : C2F_NW32;
+    const int nw = c == 16 ? C2F_NW16 : c2f_nw32(mode);
     c2f_fn fn = pick_c2f(c, mode, a.nk1);
     if (!fn || (mode == 2 && a.pair_in_co != 2 * c)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(fn, dim3((unsigned)plan.grid), dim3(nw * 64), (size_t)plan.lds_bytes, s, a);

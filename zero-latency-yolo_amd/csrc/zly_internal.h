@@ -85,11 +85,16 @@ struct C2fArgs {
     int H, W, n;
     int TH, TW, tiles_x, tiles_y, total_tiles;
     int dump;                                 // also write the intermediates that would stay in LDS to cat (debug taps)
+    void* mid; int mid_cs;                    // c = 64 with dump: the bottleneck's intermediate map (its first conv's output buffer of the unfused path)
 };
 struct C2fPlan { int th, tw, tiles_x, tiles_y, total_tiles, grid, lds_bytes; };
 bool       c2f_plan(int c, int mode, int nk1, int nk2, int cout2, int n, int H, int W, C2fPlan* plan);
 hipError_t c2f_init();
 hipError_t launch_c2f(int c, int mode, const C2fArgs& a, const C2fPlan& plan, hipStream_t s);
+// kernels_c2f64.hip -- the same for c = 64 (c2f64_kernel: 3x3 weights in registers, 1x1 weights streamed through LDS); reached through c2f_plan / launch_c2f
+bool       c2f64_plan(int mode, int nk1, int nk2, int cout2, int n, int H, int W, C2fPlan* plan);
+hipError_t c2f64_init();
+hipError_t launch_c2f64(int mode, const C2fArgs& a, const C2fPlan& plan, hipStream_t s);
 
 // kernels_misc.hip
 hipError_t launch_preprocess(int dtype, const uint8_t* src, const FrameDesc* desc, int n,
