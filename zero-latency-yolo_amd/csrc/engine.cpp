@@ -1015,7 +1015,7 @@ static int run_path(zly_engine* e, int n, const uint8_t* d_src, void* d_slabs_ou
     if (fused && e->stem1) {
         Stem1Args st = e->stem1a;
         st.st.src = d_src; st.st.desc = e->d_desc;
-        HIP_TRY(launch_stem_model1(st, n, s), ZLY_ERR_INFERENCE);
+        if (e->sw.ablate.find(",stem,") == std::string::npos) HIP_TRY(launch_stem_model1(st, n, s), ZLY_ERR_INFERENCE);      // ZLY_ABLATE_SKIP=stem (diagnostic)
         first = 3;
     } else if (fused) {
         StemArgs st = e->stem;

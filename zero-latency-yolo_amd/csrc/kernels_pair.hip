@@ -361,9 +361,20 @@ __global__ __launch_bounds__(NW * 64) void c2f_kernel(const C2fArgs a)
         if (C == 16) store4(reinterpret_cast<bf16_t*>(dst) + kq * 4, o[0]);
         else store8(reinterpret_cast<bf16_t*>(dst) + kq * 8, o[0], o[1]);
     };
-    auto put_global = [&](bf16_t* dst, const f32x4* o) {
-        if (C == 16) store4(dst + kq * 4, o[0]);
-        else store8(dst + kq * 8, o[0], o[1]);
+    // stores into the concat buffer go through a buffer resource: one 32-bit element offset per store instead of a 64-bit address pair (the
+    // 16-wave build has 128 VGPRs)
+    const __amdgpu_buffer_rsrc_t rcat = __builtin_amdgcn_make_buffer_rsrc(a.cat, 0, (unsigned)((size_t)a.n * a.H * a.W * a.cat_cs * 2), 0x00020000);
+    auto put_global = [&](int elem, const f32x4* o) {
+        if (C == 16) {
+            bf16x4 v; v[0] = (bf16_t)o[0][0]; v[1] = (bf16_t)o[0][1]; v[2] = (bf16_t)o[0][2]; v[3] = (bf16_t)o[0][3];
+            typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, v), rcat, (elem + kq * 4) * 2, 0, 0);
+        } else {
+            bf16x8 v;
+            v[0] = (bf16_t)o[0][0]; v[1] = (bf16_t)o[0][1]; v[2] = (bf16_t)o[0][2]; v[3] = (bf16_t)o[0][3];
+            v[4] = (bf16_t)o[1][0]; v[5] = (bf16_t)o[1][1]; v[6] = (bf16_t)o[1][2]; v[7] = (bf16_t)o[1][3];
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rcat, (elem + kq * 8) * 2, 0, 0);
+        }
     };
 
     // MODE 2: the bottleneck's input patch comes from the concat buffer (prefetched one tile ahead, as bottleneck_pair_kernel does)
@@ -468,7 +479,7 @@ __global__ __launch_bounds__(NW * 64) void c2f_kernel(const C2fArgs a)
                     if (interior) {
                         if (MODE == 3) put_map(ly0 + (size_t)(iy * a.TW + ix) * G::PITCH, o);
                         if (MODE == 1 || a.dump) {
-                            bf16_t* dst = cat + ((size_t)(b * a.H + gy) * a.W + gx) * a.cat_cs;
+                            const int dst = ((b * a.H + gy) * a.W + gx) * a.cat_cs;
                             put_global(dst, o);
                             put_global(dst + C, o + G::CT);
                         }
@@ -523,7 +534,7 @@ __global__ __launch_bounds__(NW * 64) void c2f_kernel(const C2fArgs a)
                 }
                 if (BACK) put_map(ly2 + (size_t)qc * G::PITCH, o);
                 if ((!BACK || a.dump) && gy < a.H && gx < a.W)
-                    put_global(cat + ((size_t)(b * a.H + gy) * a.W + gx) * a.cat_cs + a.pair_out_co, o);
+                    put_global(((b * a.H + gy) * a.W + gx) * a.cat_cs + a.pair_out_co, o);
             }
         }
 

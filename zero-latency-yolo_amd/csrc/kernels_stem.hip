@@ -16,6 +16,7 @@
 //   4. bias + SiLU, 8-byte NHWC stores: the 4 lanes of a pixel write its 32 bytes contiguously.
 #include "zly_internal.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace zly {
 
@@ -299,57 +300,103 @@ __global__ __launch_bounds__(NW * 64) void stem_model1_kernel(const Stem1Args a)
         }
     const f32x4 bias0 = *reinterpret_cast<const f32x4*>(a.st.bias + kq * 4);
     const int NR = RH * RW, ntR = (NR + 15) >> 4;
-    for (int t = wave; t < ntR; t += NW) {
-        const int q = t * 16 + p;
-        const int qc = min(q, NR - 1);
-        const int ry = div_small_s(qc, invRW), rx = qc - ry * RW;
-        const int base = (2 * ry) * PW + 2 * rx;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    // One 16-pixel tile of the region: fragments -> 2 MFMAs -> bias + SiLU -> LDS map.  Lanes beyond the region's last pixel work on a copy of
+    // it (same inputs, same result, same address: the store needs no guard), so the body has no branch and two tiles can be interleaved:
+    // every step of a tile (LDS read -> MFMA -> exp -> rcp -> store) waits for the one before, and with one tile per iteration a wave had
+    // nothing to issue meanwhile.
+    auto stem_frags = [&](int t, bf16x8 (&af)[2], int& qc, int& ry, int& rx) {
+        qc = min(t * 16 + p, NR - 1);
+        ry = div_small_s(qc, invRW); rx = qc - __mul24(ry, RW);           // 24-bit multiplies: full rate (v_mul_lo_u32 is a quarter-rate instruction)
+        const int base = __mul24(2 * ry, PW) + 2 * rx;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const bf16x4 lo = patch[base + toff[s][0]];
             const bf16x4 hi = patch[base + toff[s][1]];
-            bf16x8 af;
-            af[0] = lo[0]; af[1] = lo[1]; af[2] = lo[2]; af[3] = lo[3];
-            af[4] = hi[0]; af[5] = hi[1]; af[6] = hi[2]; af[7] = hi[3];
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(s == 0 ? w0 : w1, af, acc, 0, 0, 0);
+            af[s][0] = lo[0]; af[s][1] = lo[1]; af[s][2] = lo[2]; af[s][3] = lo[3];
+            af[s][4] = hi[0]; af[s][5] = hi[1]; af[s][6] = hi[2]; af[s][7] = hi[3];
         }
-        const int sy = sy0 + ry, sx = sx0 + rx;
-        const bool inmap = (unsigned)sy < (unsigned)a.st.Ho && (unsigned)sx < (unsigned)a.st.Wo;
+    };
+    // epilogue of a tile.  BORDER: the region reaches beyond the stem map (workgroups of the first tile row / column): those pixels are the
+    // zero padding of model.1, not conv values; the other 2/3 of the workgroups skip the test and the select.  Conversions are packed (two
+    // values per v_cvt_pk_bf16_f32) and the select acts on the packed dwords: 62 -> ~47 VALU instructions per tile of a kernel that is
+    // bound by VALU issue.
+    const bool dump = a.dump != 0;
+    auto stem_finish = [&](auto border_tag, f32x4 acc, int qc, int ry, int rx) {
+        constexpr bool BORDER = decltype(border_tag)::value;
         f32x4 v = acc + bias0;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = inmap ? v[r] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v[r] * -1.442695041f)) : 0.0f;
-        bf16x4 o;
-        o[0] = (bf16_t)v[0]; o[1] = (bf16_t)v[1]; o[2] = (bf16_t)v[2]; o[3] = (bf16_t)v[3];
-        if (q < NR) {
-            *reinterpret_cast<bf16x4*>(smap + (size_t)q * STEM1_PITCH + kq * 8) = o;
-            // debug taps: the stem pixels this tile owns (rows / columns 1 .. 2TH / 2TW of the region) also go to the model.0 tensor
-            if (a.dump && inmap && ry >= 1 && rx >= 1)
+        for (int r = 0; r < 4; ++r) v[r] = v[r] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v[r] * -1.442695041f));
+        bf16x4 o = __builtin_convertvector(v, bf16x4);
+        const int sy = sy0 + ry, sx = sx0 + rx;
+        bool inmap = true;
+        if (BORDER) {
+            inmap = (unsigned)sy < (unsigned)a.st.Ho && (unsigned)sx < (unsigned)a.st.Wo;
+            const bf16x4 z = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+            o = inmap ? o : z;
+        }
+        *reinterpret_cast<bf16x4*>(smap + __mul24(qc, STEM1_PITCH) + kq * 8) = o;
+        // debug taps: the stem pixels this tile owns (rows / columns 1 .. 2TH / 2TW of the region) also go to the model.0 tensor
+        if (dump) {
+            if (inmap && ry >= 1 && rx >= 1)
                 *reinterpret_cast<bf16x4*>(static_cast<bf16_t*>(a.st.out) + (((size_t)f * a.st.Ho + sy) * a.st.Wo + sx) * a.st.out_cs + a.st.out_co + kq * 4) = o;
         }
-    }
+    };
+    auto phase2 = [&](auto border_tag) {
+        int t = wave;
+        for (; t + NW < ntR; t += 2 * NW) {
+            bf16x8 af0[2], af1[2];
+            int q0, ry0, rx0, q1, ry1, rx1;
+            stem_frags(t, af0, q0, ry0, rx0);
+            stem_frags(t + NW, af1, q1, ry1, rx1);
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, af0[0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, af1[0], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, af0[1], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, af1[1], acc1, 0, 0, 0);
+            stem_finish(border_tag, acc0, q0, ry0, rx0);
+            stem_finish(border_tag, acc1, q1, ry1, rx1);
+        }
+        if (t < ntR) {
+            bf16x8 af0[2];
+            int q0, ry0, rx0;
+            stem_frags(t, af0, q0, ry0, rx0);
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f};
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, af0[0], acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, af0[1], acc0, 0, 0, 0);
+            stem_finish(border_tag, acc0, q0, ry0, rx0);
+        }
+    };
+    if (sy0 >= 0 && sx0 >= 0 && sy0 + RH <= a.st.Ho && sx0 + RW <= a.st.Wo) phase2(std::false_type{});
+    else phase2(std::true_type{});
     __syncthreads();
 
     // ---- 3. model.1 (3x3 s2, 16 -> 32) from the LDS map --------------------------------------------------------------------
     f32x4 b1lo = *reinterpret_cast<const f32x4*>(a.b1 + kq * 8), b1hi = *reinterpret_cast<const f32x4*>(a.b1 + kq * 8 + 4);
     const int NO = a.TH * a.TW, ntO = (NO + 15) >> 4;
     const unsigned char* wl = lw + lane * 8;
-    for (int t = wave; t < ntO; t += NW) {
-        const int q = t * 16 + p;
-        const int qc = min(q, NO - 1);
-        const int oy = div_small_s(qc, invTW), ox = qc - oy * a.TW;
-        const unsigned char* row0 = smap + ((size_t)(2 * oy) * RW + 2 * ox) * STEM1_PITCH + kq * 8;
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    // weights of both channel tiles for the 9 taps: registers for the kernel's last phase (36 VGPRs) instead of 18 LDS reads per pixel tile
+    s16x4 wa[9], wb[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        wa[k] = *reinterpret_cast<const s16x4*>(wl + (0 * 9 + k) * 512);
+        wb[k] = *reinterpret_cast<const s16x4*>(wl + (1 * 9 + k) * 512);
+    }
+    auto m1_tile = [&](int t, f32x4& acc0, f32x4& acc1, int& oy, int& ox) {
+        const int qc = min(t * 16 + p, NO - 1);
+        oy = div_small_s(qc, invTW); ox = qc - __mul24(oy, a.TW);
+        const unsigned char* row0 = smap + __mul24(__mul24(2 * oy, RW) + 2 * ox, STEM1_PITCH) + kq * 8;
+        acc0 = f32x4{0.f, 0.f, 0.f, 0.f}; acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
                 const s16x4 x = *reinterpret_cast<const s16x4*>(row0 + ((size_t)ky * RW + kx) * STEM1_PITCH);
-                const s16x4 wa = *reinterpret_cast<const s16x4*>(wl + (0 * 9 + ky * 3 + kx) * 512);
-                const s16x4 wb = *reinterpret_cast<const s16x4*>(wl + (1 * 9 + ky * 3 + kx) * 512);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wa, x, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wb, x, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wa[ky * 3 + kx], x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wb[ky * 3 + kx], x, acc1, 0, 0, 0);
             }
+    };
+    auto m1_finish = [&](int t, f32x4 acc0, f32x4 acc1, int oy, int ox) {
+        const int q = t * 16 + p;
         const int gy = oy1 + oy, gx = ox1 + ox;
         if (q < NO && gy < a.H1 && gx < a.W1) {
             f32x4 lo = acc0 + b1lo, hi = acc1 + b1hi;
@@ -363,6 +410,22 @@ __global__ __launch_bounds__(NW * 64) void stem_model1_kernel(const Stem1Args a)
             o[4] = (bf16_t)hi[0]; o[5] = (bf16_t)hi[1]; o[6] = (bf16_t)hi[2]; o[7] = (bf16_t)hi[3];
             *reinterpret_cast<bf16x8*>(static_cast<bf16_t*>(a.out1) + (((size_t)f * a.H1 + gy) * a.W1 + gx) * a.out1_cs + a.out1_co + kq * 8) = o;
         }
+    };
+    // a wave's tiles two at a time (four independent MFMA chains, two epilogues to interleave), as in phase 2
+    int t3 = wave;
+    for (; t3 + NW < ntO; t3 += 2 * NW) {
+        f32x4 a0, a1, c0, c1;
+        int oyA, oxA, oyB, oxB;
+        m1_tile(t3, a0, a1, oyA, oxA);
+        m1_tile(t3 + NW, c0, c1, oyB, oxB);
+        m1_finish(t3, a0, a1, oyA, oxA);
+        m1_finish(t3 + NW, c0, c1, oyB, oxB);
+    }
+    if (t3 < ntO) {
+        f32x4 a0, a1;
+        int oyA, oxA;
+        m1_tile(t3, a0, a1, oyA, oxA);
+        m1_finish(t3, a0, a1, oyA, oxA);
     }
 }
 
