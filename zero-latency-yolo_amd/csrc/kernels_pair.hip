@@ -269,6 +269,12 @@ __global__ __launch_bounds__(NW * 64) void bottleneck_pair_kernel(const PairArgs
 // order.  Halo pixels of cv1 are recomputed by neighbouring tiles (1.3-1.7x the cv1 work; these layers are bound by bytes
 // and SiLU issue, not by MFMAs).  With a.dump (debug taps) the intermediates are also written to the concat buffer.
 // ------------------------------------------------------------------------------------------------
+#ifdef ZLY_C2F_DIAG
+__device__ unsigned long long* g_c2f_diag = nullptr;             // diagnostic build only (tools/c2f_bench.hip): per-wave cycle sums of the phases
+#define C2FSTAMP(k) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); dsum[k] += t_ - dT0; dT0 = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define C2FSTAMP(k) do { } while (0)
+#endif
 static constexpr int C2F_BIAS_BYTES = 1024;
 template <int C, int MODE, int NW, int NLD, int NK1>
 __global__ __launch_bounds__(NW * 64) void c2f_kernel(const C2fArgs a)
@@ -282,6 +288,10 @@ __global__ __launch_bounds__(NW * 64) void c2f_kernel(const C2fArgs a)
     constexpr int T1 = 2 * C / 16;                        // cv1 output tiles (y0 | y1)
     constexpr int T2MAX = 4;                              // cv2 output tiles (Cout2 = 32 or 64)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#ifdef ZLY_C2F_DIAG
+    unsigned long long dsum[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, dT0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long dstart = dT0;
+#endif
     const int PW = a.TW + 4, PH = a.TH + 4, MW = a.TW + 2, MH = a.TH + 2;
     const int w1_bytes = FRONT ? T1 * a.nk1 * 1024 : 0;
     const int T2 = a.Cout2 >> 4;
@@ -411,6 +421,7 @@ __global__ __launch_bounds__(NW * 64) void c2f_kernel(const C2fArgs a)
     int tl = blockIdx.x;
     if (tl >= a.total_tiles) return;
     if (!FRONT) stage_load(tl);
+    C2FSTAMP(0);                                       // prologue: weight staging issued, biases, first patch loads issued
     while (true) {
         int b, y0, x0;
         tile_origin(tl, b, y0, x0);
@@ -418,9 +429,9 @@ __global__ __launch_bounds__(NW * 64) void c2f_kernel(const C2fArgs a)
         if (!FRONT) {
             stage_store();
             __syncthreads();                           // patch (and, first time, the weights) visible; previous tile's readers done
+            C2FSTAMP(1);                               // patch store + barrier
             if (tnext < a.total_tiles) stage_load(tnext);
         } else {
-            __syncthreads();                           // weights visible / previous tile's readers of lin, ly0 done
             // ---- cv1 on every pixel of the patch: x (global) -> y0 | y1 ----------------------------------------------
             const bf16_t* __restrict__ xa = static_cast<const bf16_t*>(a.x) + a.x_co;
             const bf16_t* __restrict__ xb = static_cast<const bf16_t*>(a.x2) + a.x2_co;
@@ -444,7 +455,9 @@ __global__ __launch_bounds__(NW * 64) void c2f_kernel(const C2fArgs a)
                 }
             };
             bf16x8 xcur[NK1], xnext[NK1];
-            if (wave < nt0) load_x(wave, xcur);
+            if (wave < nt0) load_x(wave, xcur);        // issued BEFORE the tile barrier: the loads touch no LDS, and the wait at the barrier (2-2.4 k cycles, c2f_bench) covers their latency
+            __syncthreads();                           // weights visible / previous tile's readers of lin, ly0 done
+            C2FSTAMP(1);
             for (int t = wave; t < nt0; t += NW) {
                 if (t + NW < nt0) load_x(t + NW, xnext);
                 const int q = t * 16 + p;
@@ -486,7 +499,9 @@ __global__ __launch_bounds__(NW * 64) void c2f_kernel(const C2fArgs a)
                     }
                 }
             }
+            C2FSTAMP(2);                               // cv1 loop
             __syncthreads();                           // y1 patch complete
+            C2FSTAMP(3);
         }
 
         // ---- conv A: patch -> intermediate map in LDS ----------------------------------------------------------------
@@ -508,7 +523,9 @@ __global__ __launch_bounds__(NW * 64) void c2f_kernel(const C2fArgs a)
             }
             if (q < NPA) put_map(lmid + (size_t)(my * MW + mx) * G::PITCH, o);
         }
+        C2FSTAMP(4);                                   // conv A loop
         __syncthreads();                               // intermediate map complete
+        C2FSTAMP(5);
 
         // ---- conv B: intermediate -> y (+ shortcut from the patch) ----------------------------------------------------
         for (int t = wave; t < ntB; t += NW) {
@@ -538,8 +555,10 @@ __global__ __launch_bounds__(NW * 64) void c2f_kernel(const C2fArgs a)
             }
         }
 
+        C2FSTAMP(6);                                   // conv B loop
         if (BACK) {
             __syncthreads();                           // y map complete
+            C2FSTAMP(7);
             // ---- cv2 over the concat [from HBM: channels below the bottleneck's input | patch interior | y] -> out -----------
             // k-step size = C (one source map per k-step); MODE 3: y0 comes from its LDS map instead of HBM
             const unsigned char* w2l = lw2 + lane * G::FRAGB;
@@ -581,10 +600,18 @@ __global__ __launch_bounds__(NW * 64) void c2f_kernel(const C2fArgs a)
                 }
             }
         }
+        C2FSTAMP(8);                                   // cv2 loop
         if (tnext >= a.total_tiles) break;
         tl = tnext;
         if (!FRONT) __syncthreads();                   // all reads of the patch / maps done before stage_store overwrites them (FRONT: barrier at loop top)
     }
+#ifdef ZLY_C2F_DIAG
+    if (lane == 0 && g_c2f_diag) {
+        unsigned long long* o = g_c2f_diag + ((size_t)blockIdx.x * NW + wave) * 16;
+        for (int i = 0; i < 9; ++i) o[i] = dsum[i];
+        o[9] = __builtin_amdgcn_s_memtime() - dstart;
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
