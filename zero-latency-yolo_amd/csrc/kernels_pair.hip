@@ -22,6 +22,7 @@
 #include "zly_internal.h"
 #include "conv_device.h"
 #include <stdlib.h>
+#include <stdio.h>
 
 namespace zly {
 
@@ -705,6 +706,7 @@ bool c2f_plan(int c, int mode, int nk1, int nk2, int cout2, int n, int H, int W,
         for (int tw = 8; tw <= 64; ++tw) {
             static const size_t lds_cap = getenv("ZLY_C2F_LDS_KB") ? (size_t)atoi(getenv("ZLY_C2F_LDS_KB")) * 1024 : (size_t)PAIR_LDS_MAX;    // tuning aid
             if (c2f_lds_bytes(c, mode, nk1, nk2, cout2, th, tw) > lds_cap) continue;
+            if (const char* ft = getenv("ZLY_C2F_TILE")) { int fth = 0, ftw = 0; if (sscanf(ft, "%d,%d", &fth, &ftw) == 2 && (fth != th || ftw != tw)) continue; }    // tuning aid: only this shape
             if (!(mode & 1) && (th + 4) * (tw + 4) * (c / 8) > nw * 64 * C2F_NLD) continue;
             const int tx = (W + tw - 1) / tw, ty = (H + th - 1) / th;
             const long tiles = (long)n * tx * ty;
