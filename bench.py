@@ -199,7 +199,7 @@ def cpu_baseline(frames_np, seconds=12.0):
     fps, p50, n, cores = out["all"]
     return {"value": round(fps, 2), "unit": "frames/s", "cores": cores, "kind": "port",
             "p50_ms": round(p50, 2),
-            "sample": f"{n} single-frame 416x416 detects (oracle C preprocess + torch-CPU fp32 YOLOv8n + oracle decode/NMS), ~{seconds / 2:.0f} s",
+            "sample": f"{n} single-frame 416x416 detects (oracle C preprocess + torch-CPU fp32 YOLOv8n + oracle decode/NMS), ~{seconds / 2:.0f} s on all cores + ~{seconds / 2:.0f} s on 2 threads",
             "value_2_threads": round(out["2"][0], 2), "p50_ms_2_threads": round(out["2"][1], 2),
             "reference_claim_fps": 60,
             "note": "ORT-CPU unavailable offline; torch-CPU stand-in for the forward pass. 60 FPS is the reference's unmeasured sleep-throttle target (README.md:16, onnx_engine.cpp:462-466)"}
