@@ -152,7 +152,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4s;
 __device__ __forceinline__ int div_small_s(int q, float inv) { return (int)(((float)q + 0.5f) * inv); }   // exact for q < 2^20, divisor < 2^10
 
 template <int NW>
-__global__ __launch_bounds__(NW * 64) void stem_model1_kernel(const Stem1Args a)
+__global__ __launch_bounds__(NW * 64, NW == 16 ? 8 : NW == 12 ? 6 : 4) void stem_model1_kernel(const Stem1Args a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem1[];
     const int RH = 2 * a.TH + 1, RW = 2 * a.TW + 1;          // stem pixels the tile needs
@@ -375,11 +375,14 @@ __global__ __launch_bounds__(NW * 64) void stem_model1_kernel(const Stem1Args a)
     const int NO = a.TH * a.TW, ntO = (NO + 15) >> 4;
     const unsigned char* wl = lw + lane * 8;
     // weights of both channel tiles for the 9 taps: registers for the kernel's last phase (36 VGPRs) instead of 18 LDS reads per pixel tile
-    s16x4 wa[9], wb[9];
+    constexpr bool WREG = NW <= 8;                           // more waves per workgroup: the register budget goes to occupancy instead
+    s16x4 wa[WREG ? 9 : 1], wb[WREG ? 9 : 1];
+    if (WREG) {
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {
-        wa[k] = *reinterpret_cast<const s16x4*>(wl + (0 * 9 + k) * 512);
-        wb[k] = *reinterpret_cast<const s16x4*>(wl + (1 * 9 + k) * 512);
+        for (int k = 0; k < 9; ++k) {
+            wa[k % (WREG ? 9 : 1)] = *reinterpret_cast<const s16x4*>(wl + (0 * 9 + k) * 512);
+            wb[k % (WREG ? 9 : 1)] = *reinterpret_cast<const s16x4*>(wl + (1 * 9 + k) * 512);
+        }
     }
     auto m1_tile = [&](int t, f32x4& acc0, f32x4& acc1, int& oy, int& ox) {
         const int qc = min(t * 16 + p, NO - 1);
@@ -391,8 +394,10 @@ __global__ __launch_bounds__(NW * 64) void stem_model1_kernel(const Stem1Args a)
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
                 const s16x4 x = *reinterpret_cast<const s16x4*>(row0 + ((size_t)ky * RW + kx) * STEM1_PITCH);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wa[ky * 3 + kx], x, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wb[ky * 3 + kx], x, acc1, 0, 0, 0);
+                const s16x4 fa = WREG ? wa[(ky * 3 + kx) % (WREG ? 9 : 1)] : *reinterpret_cast<const s16x4*>(wl + (0 * 9 + ky * 3 + kx) * 512);
+                const s16x4 fb = WREG ? wb[(ky * 3 + kx) % (WREG ? 9 : 1)] : *reinterpret_cast<const s16x4*>(wl + (1 * 9 + ky * 3 + kx) * 512);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(fa, x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(fb, x, acc1, 0, 0, 0);
             }
     };
     auto m1_finish = [&](int t, f32x4 acc0, f32x4 acc1, int oy, int ox) {
@@ -430,6 +435,7 @@ __global__ __launch_bounds__(NW * 64) void stem_model1_kernel(const Stem1Args a)
 }
 
 static constexpr int STEM1_NW = 8;
+static int stem1_nw() { static const int v = getenv("ZLY_STEM1_NW") ? atoi(getenv("ZLY_STEM1_NW")) : STEM1_NW; return (v == 12 || v == 16) ? v : STEM1_NW; }     // tuning aid
 static size_t stem1_lds_bytes(int th, int tw)
 {
     const size_t RH = 2 * th + 1, RW = 2 * tw + 1, PH = 2 * RH + 1, PW = 2 * RW + 1;
@@ -450,6 +456,10 @@ void stem1_plan(int H1, int W1, int* th, int* tw)
 
 hipError_t stem1_init()
 {
+    hipError_t r = hipFuncSetAttribute((const void*)stem_model1_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (r != hipSuccess) return r;
+    r = hipFuncSetAttribute((const void*)stem_model1_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (r != hipSuccess) return r;
     return hipFuncSetAttribute((const void*)stem_model1_kernel<STEM1_NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
@@ -459,7 +469,10 @@ hipError_t launch_stem_model1(const Stem1Args& a, int n, hipStream_t s)
     if (a.H1 * 2 != a.st.Ho || a.W1 * 2 != a.st.Wo) return hipErrorInvalidValue;      // even stem map: model.1 output = half of it
     const size_t lds = stem1_lds_bytes(a.TH, a.TW);
     if (lds > 160 * 1024 || (4 * a.TH + 3) * (4 * a.TW + 3) > STEM1_MAXIT * STEM1_NW * 64) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(stem_model1_kernel<STEM1_NW>, dim3(a.tiles_x * a.tiles_y, n), dim3(STEM1_NW * 64), lds, s, a);
+    const int nw = stem1_nw();
+    if (nw == 12) hipLaunchKernelGGL(stem_model1_kernel<12>, dim3(a.tiles_x * a.tiles_y, n), dim3(12 * 64), lds, s, a);
+    else if (nw == 16) hipLaunchKernelGGL(stem_model1_kernel<16>, dim3(a.tiles_x * a.tiles_y, n), dim3(16 * 64), lds, s, a);
+    else hipLaunchKernelGGL(stem_model1_kernel<STEM1_NW>, dim3(a.tiles_x * a.tiles_y, n), dim3(STEM1_NW * 64), lds, s, a);
     return hipGetLastError();
 }
 
