@@ -1,7 +1,7 @@
+"""Experiment: is the batch-64 step loop host-bound?  Host time to enqueue a step against the device time per step, one and three engines."""
 import os, sys, time
 import numpy as np, torch
-R="/root/repo"
-sys.path[:0] = [R+"/zero-latency-yolo_amd", R+"/zero-latency-yolo_amd/tools"]
+sys.path[:0] = [os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."), os.path.dirname(os.path.abspath(__file__))]
 import zly, zly_model as zm
 B=64
 for n_eng in (1,3):
