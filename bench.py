@@ -283,8 +283,10 @@ def run():
 
     B = a.batch
     big = 64
-    if a.size != 416 or a.scale != "n" or a.fp8:
-        a.no_extras = True
+    default_cfg = a.size == 416 and a.scale == "n" and not a.fp8
+    if not default_cfg:
+        a.no_cpu_baseline = True      # the CPU leg and the native host-to-host driver are written for BASELINE's configs[1]/[2] (YOLOv8n 416 x 416);
+                                      # the batch-1, latency and roofline legs run for every configuration
     wpath = None
     if a.scale != "n" or a.fp8:
         wpath = os.path.join(ROOT, "zero-latency-yolo_amd", "_build", f"yolov8{a.scale}_synth{'_fp8' if a.fp8 else ''}.zlyw")
@@ -348,7 +350,7 @@ def run():
         # ---- BASELINE configs[1]: batch 1, the latency path, frames resident in HBM ---------------------
         k1 = max(200, a.steps * 2)
         log(f"headline {value:.0f} frames/s (blocks ms/step: {result['blocks_ms_per_step']}); batch-1 leg")
-        bt1 = timed_blocks(engs[:1], sets_1, 1, k1, max(20, a.warmup), 5, slab_bufs(1), sp, world, gather_bufs(1))      # the latency path: ONE in-order chain
+        bt1 = timed_blocks(engs[:1], sets_1, 1, k1, max(20, a.warmup), 5, slab_bufs(1), sp, world, gather_bufs(1), a.size)      # the latency path: ONE in-order chain
         dt1 = float(np.median(bt1))
         lat_b1 = {"value": round(world * k1 / dt1, 1), "unit": "frames/s", "steps": k1, "ms_per_step_device_resident": round(dt1 / k1 * 1e3, 5)}
         if rank == 0:
@@ -366,7 +368,7 @@ def run():
             lat_b1.update({"p50_detect_ms_host_to_host": round(float(np.percentile(lat, 50)), 4),
                            "p90_detect_ms_host_to_host": round(float(np.percentile(lat, 90)), 4),
                            "p99_detect_ms_host_to_host": round(float(np.percentile(lat, 99)), 4), "samples": len(lat),
-                           "path": "zly_detect: 519 KB H2D over PCIe + path + slab D2H, synchronous"})
+                           "path": f"zly_detect: {a.size * a.size * 3 // 1000} KB H2D over PCIe + path + slab D2H, synchronous"})
             # ---- roofline of the dominant kernel family (the MFMA conv launches of one forward) ----------
             log("roofline leg (per-op hipEvent profile)")
             ops = eng.ops()
@@ -378,9 +380,9 @@ def run():
             # `achieved` uses the first (conservative, rocprof-consistent); the second is reported beside it.
             for nb, frames in ((B, sets_b[0]), (1, sets_1[0])):
                 os.environ["ZLY_PROFILE_INNER"] = "8"
-                ms8 = eng.profile_ops(frames.data_ptr(), nb, 416, 416, reps=10)
+                ms8 = eng.profile_ops(frames.data_ptr(), nb, a.size, a.size, reps=10)
                 os.environ["ZLY_PROFILE_INNER"] = "1"
-                ms = eng.profile_ops(frames.data_ptr(), nb, 416, 416, reps=20)
+                ms = eng.profile_ops(frames.data_ptr(), nb, a.size, a.size, reps=20)
                 rows = per_launch_roofline(ops, eng.op_kernels(nb), eng.launches(nb), ms, nb)
                 conv_l = [r for r in rows if r["is_conv"]]
                 dom = max(conv_l, key=lambda r: r["us"])
@@ -440,7 +442,7 @@ def run():
             # --pmc passes, gfx950 correction applied; see the file for provenance): per batch-64 step
             for tp in ("r03_traffic_b64.json", "r02_traffic_b64.json"):
                 tpath = os.path.join(ROOT, "profiles", tp)
-                if B == 64 and os.path.exists(tpath):
+                if B == 64 and default_cfg and os.path.exists(tpath):
                     tj = json.load(open(tpath))
                     roof[B]["traffic"] = tj["traffic_bytes_per_step"]
                     roof[B]["traffic_over_fused_algorithmic"] = round(tj["traffic_bytes_per_step"] / (roof[B]["algorithmic_GB_per_step_fused"] * 1e9), 3)
@@ -476,7 +478,7 @@ def run():
         assert torch.equal(mine, ref_slab), "gathered slabs of the last step differ from a single-engine run on the same frames"
         result["gather"] = {"ranks": world, "bytes_per_rank_per_step": B * sb, "frames_checked": int(hd.shape[0]), "equals_single_engine_run": True}
         dist.barrier()
-    if rank == 0 and world == 1 and not a.no_extras and os.environ.get("ZLY_BENCH_NO_H2H") != "1":
+    if rank == 0 and world == 1 and not a.no_extras and default_cfg and os.environ.get("ZLY_BENCH_NO_H2H") != "1":
         for e_ in engs:                # the native driver creates its own engines: free this process's first
             e_.close()
         engs = []
