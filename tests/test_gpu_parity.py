@@ -653,6 +653,10 @@ def test_yolov8s_640_fp8_weights(tmp_path, oracle):
         dets, n = e.detect(f, cap=1024)
         own = oracle.postprocess(e.head_tensor(0), 640, 640, 0.5, 0.45)
         assert n == len(own) and det_fields_equal(dets, own[:1024])
+        # the detect path's front for the 32-channel stem (stem_fused_kernel<2>: preprocess + model.0 in one kernel, pair-permuted rows):
+        # the head tensor it leads to must be the forward pass of the preprocessed frame within the bf16 tolerance
+        _assert_bf16_close(e.head_tensor(0)[None], want32[i][None])
+        _assert_layer_close(e.tap("model.0", 0), ref16.taps["model.0"][i].numpy(), f"model.0 of frame {i} (fused stem, 32 channels)")
     e.close()
     e = zly.Engine(zly.DEFAULT_WEIGHTS, warmup_runs=0)
     assert not e.weights_fp8

@@ -273,13 +273,13 @@ struct PlanBuilder {
         return true;
     }
     // repack + upload the weights of a conv that is executed inside another kernel (fused Detect tail)
-    bool pack_only(const std::string& name, int cin_store, size_t* w_off, size_t* b_off, int* nk) {
+    bool pack_only(const std::string& name, int cin_store, size_t* w_off, size_t* b_off, int* nk, bool pair_rows = false) {
         const ConvRec* r = e->model.find(name);
         if (!r) { err = "conv missing from model file: " + name; return false; }
         std::vector<uint8_t> w;
         std::vector<float> b;
         int cout = 0, cout_pad = 0;
-        repack_conv({r}, cin_store, kstep, e->dtype == ZLY_DTYPE_BF16, &w, &b, &cout, &cout_pad, nk);
+        repack_conv({r}, cin_store, kstep, e->dtype == ZLY_DTYPE_BF16, &w, &b, &cout, &cout_pad, nk, pair_rows);
         *w_off = append(w.data(), w.size());
         *b_off = append(b.data(), b.size() * sizeof(float));
         return true;
@@ -424,11 +424,11 @@ static int build_plan(zly_engine* e, std::string* err)
     ok = ok && pb.conv({"model.0"}, View{e->in_buf, 0, 8}, View{a0, 0, ch[0]});
     size_t stem_w = 0, stem_b = 0;
     int stem_nk = 0;
-    e->stem_fused = e->dtype == ZLY_DTYPE_BF16 && ch[0] == 16;
-    if (e->stem_fused) ok = ok && pb.pack_only("model.0", 4, &stem_w, &stem_b, &stem_nk) && stem_nk == 2;
+    e->stem_fused = e->dtype == ZLY_DTYPE_BF16 && (ch[0] == 16 || ch[0] == 32);          // YOLOv8n / YOLOv8-s stems: preprocess + model.0 in one kernel
+    if (e->stem_fused) ok = ok && pb.pack_only("model.0", 4, &stem_w, &stem_b, &stem_nk, ch[0] == 32) && stem_nk == 2;
     ok = ok && pb.conv({"model.1"}, View{a0, 0, ch[0]}, View{a1, 0, ch[1]});
     size_t m1_w = 0, m1_b = 0;
-    e->stem1 = e->stem_fused && ch[1] == 32 && !(e->cfg.flags & ZLY_FLAG_NO_FUSION) && getenv("ZLY_NO_STEM1") == nullptr && ok;
+    e->stem1 = e->stem_fused && ch[0] == 16 && ch[1] == 32 && !(e->cfg.flags & ZLY_FLAG_NO_FUSION) && getenv("ZLY_NO_STEM1") == nullptr && ok;
     if (e->stem1) {
         // model.1 in the fused kernel's tiling: one 16x16x16 MFMA per tap (k = ci), pair-permuted rows, bias in channel order
         const ConvRec* r = m.find("model.1");

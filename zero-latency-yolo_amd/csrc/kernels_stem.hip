@@ -29,6 +29,9 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define STEM_PH (STEM_TH * 2 + 1)
 #define STEM_PW (STEM_TW * 2 + 1)
 
+// NT = output channel tiles of 16: 1 (YOLOv8n, 16-channel stem: rows in channel order) or 2 (YOLOv8-s, 32 channels: pair-permuted rows, a lane
+// ends with 8 consecutive channels = one 16-byte store); the pixel fragments are read once for both tiles
+template <int NT>
 __global__ __launch_bounds__(256) void stem_fused_kernel(const StemArgs a)
 {
     __shared__ __attribute__((aligned(16))) bf16x4 patch[STEM_PH * STEM_PW];
@@ -41,9 +44,12 @@ __global__ __launch_bounds__(256) void stem_fused_kernel(const StemArgs a)
     const int oy0 = ty * STEM_TH, ox0 = tx * STEM_TW;
     const int iy0 = oy0 * 2 - 1, ix0 = ox0 * 2 - 1;
 
-    // weight fragments: tiled [1][2][lane][8] (k = tap*4 + c), resident in registers
-    const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(static_cast<const bf16_t*>(a.wgt) + lane * 8);
-    const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(static_cast<const bf16_t*>(a.wgt) + 512 + lane * 8);
+    // weight fragments: tiled [NT][2][lane][8] (k = tap*4 + c), resident in registers
+    bf16x8 w[NT][2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) w[t][s] = *reinterpret_cast<const bf16x8*>(static_cast<const bf16_t*>(a.wgt) + (t * 2 + s) * 512 + lane * 8);
 
     const FrameDesc d = a.desc[f];
     const float scale_w = (float)d.w / (float)a.tw;
@@ -89,12 +95,16 @@ __global__ __launch_bounds__(256) void stem_fused_kernel(const StemArgs a)
             toff[s][j] = ky * STEM_PW + kx;
         }
 
-    const f32x4 bias = *reinterpret_cast<const f32x4*>(a.bias + kq * 4);
+    f32x4 bias[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bias[t] = *reinterpret_cast<const f32x4*>(a.bias + (NT == 1 ? kq * 4 : kq * 8 + t * 4));
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int row = wave * 4 + (i >> 1), col = (i & 1) * 16 + p;
         const int base = (row * 2) * STEM_PW + col * 2;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        f32x4 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const bf16x4 lo = patch[base + toff[s][0]];
@@ -102,26 +112,39 @@ __global__ __launch_bounds__(256) void stem_fused_kernel(const StemArgs a)
             bf16x8 af;
             af[0] = lo[0]; af[1] = lo[1]; af[2] = lo[2]; af[3] = lo[3];
             af[4] = hi[0]; af[5] = hi[1]; af[6] = hi[2]; af[7] = hi[3];
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(s == 0 ? w0 : w1, af, acc, 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[t][s], af, acc[t], 0, 0, 0);
         }
         const int oy = oy0 + row, ox = ox0 + col;
-        if (oy < a.Ho && ox < a.Wo && kq * 4 < a.Cout) {
-            f32x4 v = acc + bias;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = v[r] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v[r] * -1.442695041f));
-            bf16x4 o;
-            o[0] = (bf16_t)v[0]; o[1] = (bf16_t)v[1]; o[2] = (bf16_t)v[2]; o[3] = (bf16_t)v[3];
+        if (oy < a.Ho && ox < a.Wo) {
             const int m = (f * a.Ho + oy) * a.Wo + ox;
-            *reinterpret_cast<bf16x4*>(static_cast<bf16_t*>(a.out) + (m * a.out_cs + a.out_co + kq * 4)) = o;
+            bf16_t* dst = static_cast<bf16_t*>(a.out) + (m * a.out_cs + a.out_co);
+            bf16x4 o[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                f32x4 v = acc[t] + bias[t];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = v[r] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v[r] * -1.442695041f));
+                o[t] = __builtin_convertvector(v, bf16x4);
+            }
+            if (NT == 1) *reinterpret_cast<bf16x4*>(dst + kq * 4) = o[0];
+            else {
+                bf16x8 o8;
+                o8[0] = o[0][0]; o8[1] = o[0][1]; o8[2] = o[0][2]; o8[3] = o[0][3];
+                o8[4] = o[NT - 1][0]; o8[5] = o[NT - 1][1]; o8[6] = o[NT - 1][2]; o8[7] = o[NT - 1][3];
+                *reinterpret_cast<bf16x8*>(dst + kq * 8) = o8;
+            }
         }
     }
 }
 
 hipError_t launch_stem_fused(const StemArgs& a, int n, hipStream_t s)
 {
-    if (a.Cout != 16) return hipErrorInvalidValue;         // one 16-channel MFMA tile (YOLOv8n); wider stems use the generic path
+    if (a.Cout != 16 && a.Cout != 32) return hipErrorInvalidValue;         // one or two 16-channel MFMA tiles (YOLOv8n / YOLOv8-s); wider stems use the generic path
+    if (a.Cout == 32 && (a.out_cs % 8 || a.out_co % 8)) return hipErrorInvalidValue;
     const int tiles_y = (a.Ho + STEM_TH - 1) / STEM_TH;
-    hipLaunchKernelGGL(stem_fused_kernel, dim3(a.tiles_x * tiles_y, n), dim3(256), 0, s, a);
+    if (a.Cout == 16) hipLaunchKernelGGL(stem_fused_kernel<1>, dim3(a.tiles_x * tiles_y, n), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(stem_fused_kernel<2>, dim3(a.tiles_x * tiles_y, n), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
