@@ -84,6 +84,28 @@ __device__ __forceinline__ float iou_cxcywh(const Cand& a, const Cand& b)
     return (uni > 0) ? inter / uni : 0.0f;
 }
 
+// The same arithmetic with the per-box part hoisted: corners and area depend on one box only, so a loop that tests one box against many
+// computes them once per box (identical expressions, identical values; FP contraction is off) and the pair part per pair.
+struct BoxC { float x0, y0, x1, y1, area; };
+__device__ __forceinline__ BoxC boxc(const Cand& a)
+{
+    BoxC r;
+    r.x0 = a.x - a.w / 2; r.y0 = a.y - a.h / 2; r.x1 = a.x + a.w / 2; r.y1 = a.y + a.h / 2;
+    r.area = a.w * a.h;
+    return r;
+}
+__device__ __forceinline__ float iou_boxc(const BoxC& a, const BoxC& b)
+{
+    const float lo_x = (a.x0 < b.x0) ? b.x0 : a.x0, hi_x = (b.x1 < a.x1) ? b.x1 : a.x1;   // std::max / std::min
+    const float lo_y = (a.y0 < b.y0) ? b.y0 : a.y0, hi_y = (b.y1 < a.y1) ? b.y1 : a.y1;
+    const float dx = hi_x - lo_x, dy = hi_y - lo_y;
+    const float ox = (0.0f < dx) ? dx : 0.0f;
+    const float oy = (0.0f < dy) ? dy : 0.0f;
+    const float inter = ox * oy;
+    const float uni = a.area + b.area - inter;
+    return (uni > 0) ? inter / uni : 0.0f;
+}
+
 // total order of applyNMS's sort (:846-851) with the anchor index breaking exact ties
 __device__ __forceinline__ bool cand_before(const Cand& a, const Cand& b)
 {
@@ -191,11 +213,12 @@ __device__ void nms_general(const Cand* gsrc, int n, float iou_thr, int nc, Cand
                 else { me.x = me.y = me.w = me.h = 0.f; me.conf = 0.f; me.cls = c; me.anchor = 0; me.pad_ = 1; }
                 unsigned long long alive = __ballot(valid && me.pad_ == 0);
                 const int nb = min(64, e - i0);
+                const BoxC mc = boxc(me);
                 for (int i = 0; i < nb - 1; ++i) {
                     if (!((alive >> i) & 1ull)) continue;                  // wave-uniform
-                    Cand bi;
-                    bi.x = rl_f(me.x, i); bi.y = rl_f(me.y, i); bi.w = rl_f(me.w, i); bi.h = rl_f(me.h, i);
-                    const bool kill = lane > i && ((alive >> lane) & 1ull) && iou_cxcywh(bi, me) > iou_thr;
+                    BoxC bi;
+                    bi.x0 = rl_f(mc.x0, i); bi.y0 = rl_f(mc.y0, i); bi.x1 = rl_f(mc.x1, i); bi.y1 = rl_f(mc.y1, i); bi.area = rl_f(mc.area, i);
+                    const bool kill = lane > i && ((alive >> lane) & 1ull) && iou_boxc(bi, mc) > iou_thr;
                     alive &= ~__ballot(kill);
                 }
                 if (valid && me.pad_ == 0 && !((alive >> lane) & 1ull)) sorted[idx].pad_ = 1;
@@ -206,12 +229,22 @@ __device__ void nms_general(const Cand* gsrc, int n, float iou_thr, int nc, Cand
             const unsigned long long alive = ((unsigned long long)(unsigned)wave_tot[1] << 32) | (unsigned long long)(unsigned)wave_tot[0];
             for (int j = i0 + 64 + tid; j < e; j += NMS_THREADS) {
                 if (sorted[j].pad_) continue;
-                const Cand cj = sorted[j];
+                const BoxC cj = boxc(sorted[j]);
                 unsigned long long m = alive;
+                // four survivors per step: the IoU is one long dependent chain (an IEEE divide at its end), and a thread that walks the
+                // survivors one at a time waits out every chain alone -- four independent chains interleave (which survivor suppresses a
+                // candidate does not matter, only whether one does)
                 while (m) {
-                    const int i = __builtin_ctzll(m);
-                    m &= m - 1ull;
-                    if (iou_cxcywh(sorted[i0 + i], cj) > iou_thr) { sorted[j].pad_ = 1; break; }
+                    int ii[4];
+                    bool hit = false;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { ii[k] = m ? __builtin_ctzll(m) : -1; if (m) m &= m - 1ull; }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const BoxC bi = boxc(sorted[i0 + (ii[k] < 0 ? ii[0] : ii[k])]);
+                        hit = hit || (iou_boxc(bi, cj) > iou_thr);
+                    }
+                    if (hit) { sorted[j].pad_ = 1; break; }
                 }
             }
             if (!in_lds) __threadfence();
@@ -224,11 +257,11 @@ __device__ void nms_general(const Cand* gsrc, int n, float iou_thr, int nc, Cand
             if (s < 0 || e - s < 2 || e - s > NMS_BIG_CLASS) continue;
             for (int i = s; i < e - 1; ++i) {
                 if (*reinterpret_cast<volatile int*>(&sorted[i].pad_)) continue;       // wave-uniform
-                const Cand bi = sorted[i];
+                const BoxC bi = boxc(sorted[i]);
                 for (int j = i + 1 + lane; j < e; j += 64) {
                     volatile int* rj = reinterpret_cast<volatile int*>(&sorted[j].pad_);
                     if (*rj) continue;
-                    if (iou_cxcywh(bi, sorted[j]) > iou_thr) *rj = 1;
+                    if (iou_boxc(bi, boxc(sorted[j])) > iou_thr) *rj = 1;
                 }
                 if (!in_lds) __threadfence();
                 __builtin_amdgcn_wave_barrier();
@@ -319,17 +352,18 @@ __device__ __forceinline__ void nms_wave(const Cand* __restrict__ gsrc, int n, f
     unsigned long long aliveB = nB >= 64 ? ~0ull : ((1ull << nB) - 1ull);
     unsigned long long todoA = __ballot(lane < nA && nxa == a.cls);
     unsigned long long todoB = __ballot(lane < nB && nxb == b.cls);
+    const BoxC ca = boxc(a), cb = boxc(b);                   // corners + area once per candidate, not once per pair
     while (todoA) {
         const int i = __builtin_ctzll(todoA);
         todoA &= todoA - 1ull;
         if (!((aliveA >> i) & 1ull)) continue;               // wave-uniform
-        Cand bi;
-        bi.x = rl_f(a.x, i); bi.y = rl_f(a.y, i); bi.w = rl_f(a.w, i); bi.h = rl_f(a.h, i);
+        BoxC bi;
+        bi.x0 = rl_f(ca.x0, i); bi.y0 = rl_f(ca.y0, i); bi.x1 = rl_f(ca.x1, i); bi.y1 = rl_f(ca.y1, i); bi.area = rl_f(ca.area, i);
         const int ci = rl_i(a.cls, i);
-        const bool killA = lane > i && a.cls == ci && iou_cxcywh(bi, a) > iou_thr;
+        const bool killA = lane > i && a.cls == ci && iou_boxc(bi, ca) > iou_thr;
         aliveA &= ~__ballot(killA);
         if (two) {
-            const bool killB = b.cls == ci && iou_cxcywh(bi, b) > iou_thr;
+            const bool killB = b.cls == ci && iou_boxc(bi, cb) > iou_thr;
             aliveB &= ~__ballot(killB);
         }
     }
@@ -337,10 +371,10 @@ __device__ __forceinline__ void nms_wave(const Cand* __restrict__ gsrc, int n, f
         const int i = __builtin_ctzll(todoB);
         todoB &= todoB - 1ull;
         if (!((aliveB >> i) & 1ull)) continue;
-        Cand bi;
-        bi.x = rl_f(b.x, i); bi.y = rl_f(b.y, i); bi.w = rl_f(b.w, i); bi.h = rl_f(b.h, i);
+        BoxC bi;
+        bi.x0 = rl_f(cb.x0, i); bi.y0 = rl_f(cb.y0, i); bi.x1 = rl_f(cb.x1, i); bi.y1 = rl_f(cb.y1, i); bi.area = rl_f(cb.area, i);
         const int ci = rl_i(b.cls, i);
-        const bool killB = lane > i && b.cls == ci && iou_cxcywh(bi, b) > iou_thr;
+        const bool killB = lane > i && b.cls == ci && iou_boxc(bi, cb) > iou_thr;
         aliveB &= ~__ballot(killB);
     }
     const unsigned long long below = (1ull << lane) - 1ull;
@@ -468,11 +502,12 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const Cand* __restrict
         __builtin_amdgcn_wave_barrier();
         if (lane < L) me = lds_c[s + lane];                  // lane j now holds the j-th candidate of the sorted class
         unsigned long long alive = L >= 64 ? ~0ull : ((1ull << L) - 1ull);
+        const BoxC mc = boxc(me);
         for (int i = 0; i < L - 1; ++i) {
             if (!((alive >> i) & 1ull)) continue;            // wave-uniform
-            Cand bi;
-            bi.x = __shfl(me.x, i); bi.y = __shfl(me.y, i); bi.w = __shfl(me.w, i); bi.h = __shfl(me.h, i);
-            const bool kill = lane > i && lane < L && iou_cxcywh(bi, me) > iou_thr;
+            BoxC bi;
+            bi.x0 = rl_f(mc.x0, i); bi.y0 = rl_f(mc.y0, i); bi.x1 = rl_f(mc.x1, i); bi.y1 = rl_f(mc.y1, i); bi.area = rl_f(mc.area, i);
+            const bool kill = lane > i && lane < L && iou_boxc(bi, mc) > iou_thr;
             alive &= ~__ballot(kill);
         }
         // park the result: survivors first (sorted order), count in cls_cnt
