@@ -123,6 +123,28 @@ def test_postprocess_many_candidates_in_one_class(eng16, oracle):
     assert n_cand == 3000 and n_kept == len(want) and det_fields_equal(got, want)
 
 
+@pytest.mark.parametrize("n_one,n_other,box", [(129, 0, 40.0), (192, 30, 12.0), (500, 100, 12.0), (600, 60, 60.0), (1000, 24, 20.0), (1020, 4, 6.0),
+                                               (1100, 50, 12.0), (1500, 200, 30.0)])
+def test_postprocess_crowded_class_blocks(eng16, oracle, n_one, n_other, box):
+    """One class holding hundreds of candidates (a crowd): the path that resolves such a class by the whole workgroup in blocks of 64 sorted
+    candidates -- in LDS up to 1024 candidates per frame, in global memory beyond -- with small boxes (most are kept: long chains of kept
+    boxes across blocks) and large ones (most are suppressed, many by boxes of earlier blocks), next to a few sparse classes."""
+    rng = np.random.default_rng(1000 + n_one)
+    n = n_one + n_other
+    head = np.zeros((4 + 6, n), dtype=np.float32)
+    head[0] = rng.uniform(0, 416, n); head[1] = rng.uniform(0, 416, n)
+    head[2] = rng.uniform(box / 2, box, n); head[3] = rng.uniform(box / 2, box, n)
+    head[4, :n_one] = rng.uniform(0.5, 1.0, n_one)
+    head[4, :8] = 0.75                                        # exact confidence ties inside the crowded class (anchor order decides)
+    if n_other:
+        head[5 + rng.integers(0, 5, n_other), np.arange(n_one, n)] = rng.uniform(0.5, 1.0, n_other)
+    perm = rng.permutation(n)
+    head = np.ascontiguousarray(head[:, perm])
+    want = oracle.postprocess(head, 416, 416)
+    got, n_kept, n_cand = eng16.postprocess(head, 416, 416)
+    assert n_cand == n and n_kept == len(want) and det_fields_equal(got, want)
+
+
 def test_postprocess_ties_threshold_and_empty(eng16, oracle):
     head = np.zeros((4 + 4, 8), dtype=np.float32)
     head[0] = [50, 60, 300, 300, 300, 100, 100, 100]; head[1] = 100
