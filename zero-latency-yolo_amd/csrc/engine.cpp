@@ -1623,6 +1623,7 @@ int32_t zly_create(const zly_config* cfg, zly_engine** out)
         HIP_TRY(pair_init(), ZLY_ERR_SYSTEM);
         HIP_TRY(stem1_init(), ZLY_ERR_SYSTEM);
         HIP_TRY(c2f_init(), ZLY_ERR_SYSTEM);
+        HIP_TRY(nms_init(), ZLY_ERR_SYSTEM);
         // ZLY_CU_PART="i/n": this engine's streams only use the i-th of n equal slices of the chip's compute units (spatial
         // partitioning: several engines run side by side, the launch-latency-bound small-map layers of one beside the
         // bandwidth-bound layers of another).  Experiment switch: see DESIGN.md section 5.

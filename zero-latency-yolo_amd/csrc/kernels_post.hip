@@ -151,7 +151,7 @@ __device__ __forceinline__ int rl_i(int v, int l) { return __builtin_amdgcn_read
 // keys: the sort keys of the frame's candidates staged in LDS (class | confidence | anchor; nullptr when they do not fit): the rank loop
 // compares every candidate with every other one, and reading the others from global memory -- 600 dependent L2 round trips per thread for the
 // 600 candidates of a crowded frame -- was 0.77 ms of a 2.4 ms YOLOv8-s 640 x 640 step (profiles/r03_bench_yolov8s_640_b32.json)
-__device__ void nms_general(const Cand* gsrc, int n, float iou_thr, int nc, Cand* sorted, bool in_lds, int* keys,
+__device__ void nms_general(const Cand* gsrc, int n, float iou_thr, int nc, Cand* sorted, bool in_lds, int* keys, int kcap,
                             int* seg_start, int* seg_end, int* wave_tot, int* run_base, zly_det* dets, int cap, int* n_kept_out)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -163,7 +163,7 @@ __device__ void nms_general(const Cand* gsrc, int n, float iou_thr, int nc, Cand
             Cand c;
             if (i < n) c = gsrc[i];
             else { c.cls = 0x7fffffff; c.conf = 0.f; c.anchor = 0x7fffffff; }          // padding: sorts behind every real candidate
-            keys[i] = c.cls; keys[NMS_LDS_CAP + i] = __float_as_int(c.conf); keys[2 * NMS_LDS_CAP + i] = c.anchor;
+            keys[i] = c.cls; keys[kcap + i] = __float_as_int(c.conf); keys[2 * kcap + i] = c.anchor;
         }
     }
     __syncthreads();
@@ -174,8 +174,8 @@ __device__ void nms_general(const Cand* gsrc, int n, float iou_thr, int nc, Cand
             typedef __attribute__((ext_vector_type(4))) int i32x4;
             for (int j = 0; j < n4; j += 4) {                        // four candidates per step: three 16-byte broadcast reads
                 const i32x4 kc = *reinterpret_cast<const i32x4*>(keys + j);
-                const i32x4 kf = *reinterpret_cast<const i32x4*>(keys + NMS_LDS_CAP + j);
-                const i32x4 ka = *reinterpret_cast<const i32x4*>(keys + 2 * NMS_LDS_CAP + j);
+                const i32x4 kf = *reinterpret_cast<const i32x4*>(keys + kcap + j);
+                const i32x4 ka = *reinterpret_cast<const i32x4*>(keys + 2 * kcap + j);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     Cand o;
@@ -390,17 +390,21 @@ __device__ __forceinline__ void nms_wave(const Cand* __restrict__ gsrc, int n, f
     if (lane == 0) *n_kept_out = keptA + __popcll(aliveB);
 }
 
+// CAP = candidates of a frame that the LDS paths hold: NMS_LDS_CAP (56 KB of LDS) for models of up to 4096 anchors, twice that (100 KB,
+// dynamic) for larger ones (640 x 640: 8400 anchors) -- a frame beyond CAP takes the global-memory path, 2-3x slower
+template <int CAP>
 __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const Cand* __restrict__ cand_all, int* __restrict__ cand_count,
                                                           int N, float iou_thr, int nc, Cand* __restrict__ scratch_all,
                                                           unsigned char* __restrict__ slabs, int cap, uint32_t tag0, int force_general)
 {
-    __shared__ Cand lds_c[NMS_LDS_CAP];           // class-bucketed candidates (general path: sorted list)
+    extern __shared__ __attribute__((aligned(16))) unsigned char nms_dyn[];
+    Cand* lds_c = reinterpret_cast<Cand*>(nms_dyn);                                  // [CAP] class-bucketed candidates (general path: sorted list)
+    int* lds_keys = reinterpret_cast<int*>(nms_dyn + (size_t)CAP * sizeof(Cand));     // [3 * CAP] general path: sort keys (class | confidence bits | anchor)
     __shared__ int cls_cnt[NMS_MAX_CLASSES];      // candidates per class -> later: kept per class
     __shared__ int cls_off[NMS_MAX_CLASSES];      // segment start per class
     __shared__ int cls_fill[NMS_MAX_CLASSES];     // scatter cursor / general path seg_end
     __shared__ int wave_tot[NMS_WAVES];
     __shared__ int sh_misc[4];                    // [0] max class count, [1] run_base, [2] n_kept
-    __shared__ __attribute__((aligned(16))) int lds_keys[3 * NMS_LDS_CAP];     // general path: sort keys (class | confidence bits | anchor)
 
     const int f = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -427,12 +431,12 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const Cand* __restrict
     __syncthreads();
     if (tid == 0) cand_count[f] = 0;       // self-cleaning: the next frame's decode appends from 0 again (no memset launch)
 
-    bool fast = n <= NMS_LDS_CAP;
-    Cand mine[(NMS_LDS_CAP + NMS_THREADS - 1) / NMS_THREADS];
+    bool fast = n <= CAP;
+    Cand mine[(CAP + NMS_THREADS - 1) / NMS_THREADS];
     if (fast) {
         // 1. histogram
 #pragma unroll
-        for (int k = 0; k < (NMS_LDS_CAP + NMS_THREADS - 1) / NMS_THREADS; ++k) {
+        for (int k = 0; k < (CAP + NMS_THREADS - 1) / NMS_THREADS; ++k) {
             const int i = tid + k * NMS_THREADS;
             if (i < n) { mine[k] = gsrc[i]; atomicAdd(&cls_cnt[mine[k].cls], 1); }
         }
@@ -459,9 +463,9 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const Cand* __restrict
     }
     if (!fast) {
         // general path (uniform per workgroup)
-        const bool in_lds = n <= NMS_LDS_CAP;
+        const bool in_lds = n <= CAP;
         __syncthreads();
-        nms_general(gsrc, n, iou_thr, nc, in_lds ? lds_c : scratch_all + (size_t)f * N, in_lds, in_lds ? lds_keys : nullptr,
+        nms_general(gsrc, n, iou_thr, nc, in_lds ? lds_c : scratch_all + (size_t)f * N, in_lds, in_lds ? lds_keys : nullptr, CAP,
                     cls_off, cls_fill, wave_tot, &sh_misc[1], dets, cap, &sh_misc[2]);
         __syncthreads();
         if (tid == 0) {
@@ -473,7 +477,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const Cand* __restrict
 
     // scatter into class segments
 #pragma unroll
-    for (int k = 0; k < (NMS_LDS_CAP + NMS_THREADS - 1) / NMS_THREADS; ++k) {
+    for (int k = 0; k < (CAP + NMS_THREADS - 1) / NMS_THREADS; ++k) {
         const int i = tid + k * NMS_THREADS;
         if (i < n) {
             const int c = mine[k].cls;
@@ -549,13 +553,26 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const Cand* __restrict
     }
 }
 
+static bool g_nms_big_ok = false;
+// dynamic LDS above 64 KiB needs an opt-in per kernel; done once at engine creation, outside any stream capture
+hipError_t nms_init()
+{
+    g_nms_big_ok = hipFuncSetAttribute((const void*)nms_kernel<2 * NMS_LDS_CAP>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        2 * NMS_LDS_CAP * (int)(sizeof(Cand) + 12)) == hipSuccess;
+    return hipSuccess;
+}
+
 hipError_t launch_nms(const Cand* cand, int* cand_count, int N, int n, float iou_thr, int nc,
                       Cand* scratch, void* slabs, int cap, uint32_t tag0, hipStream_t s)
 {
     if (nc > NMS_MAX_CLASSES) return hipErrorInvalidValue;
     static const int force_general = getenv("ZLY_NMS_GENERAL") != nullptr ? 1 : 0;     // tests / A-B: every frame on the eight-wave path
-    hipLaunchKernelGGL(nms_kernel, dim3(n), dim3(NMS_THREADS), 0, s, cand, cand_count, N, iou_thr, nc, scratch,
-                       (unsigned char*)slabs, cap, tag0, force_general);
+    if (N > 4096 && g_nms_big_ok)
+        hipLaunchKernelGGL(nms_kernel<2 * NMS_LDS_CAP>, dim3(n), dim3(NMS_THREADS), (size_t)2 * NMS_LDS_CAP * (sizeof(Cand) + 12), s, cand, cand_count, N, iou_thr, nc,
+                           scratch, (unsigned char*)slabs, cap, tag0, force_general);
+    else
+        hipLaunchKernelGGL(nms_kernel<NMS_LDS_CAP>, dim3(n), dim3(NMS_THREADS), (size_t)NMS_LDS_CAP * (sizeof(Cand) + 12), s, cand, cand_count, N, iou_thr, nc,
+                           scratch, (unsigned char*)slabs, cap, tag0, force_general);
     return hipGetLastError();
 }
 

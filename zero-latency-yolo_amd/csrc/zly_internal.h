@@ -153,6 +153,7 @@ hipError_t launch_head_fused(int dtype, const HeadArgs& a, int n, hipStream_t s)
 struct Cand { float x, y, w, h; float conf; int cls; int anchor; int pad_; };   // 32 bytes
 hipError_t launch_decode(const float* head, int nc, int N, int n, const FrameDesc* desc, float conf_thr,
                          Cand* cand, int* cand_count, hipStream_t s);
+hipError_t nms_init();
 hipError_t launch_nms(const Cand* cand, int* cand_count, int N, int n, float iou_thr, int nc,
                       Cand* scratch, void* slabs, int cap, uint32_t tag0, hipStream_t s);
 

@@ -32,7 +32,7 @@ static void run(const char* name, int frames, int n, int big_class_share_pct, in
     for (int rep = 0; rep < 8; ++rep) {
         hipMemcpy(dc, cnt.data(), frames * 4, hipMemcpyHostToDevice);
         hipEventRecord(e0, 0);
-        launch_nms(d, dc, N, frames, 0.45f, nc, scratch, slabs, cap, 0, 0);
+        nms_init(); launch_nms(d, dc, N, frames, 0.45f, nc, scratch, slabs, cap, 0, 0);
         hipEventRecord(e1, 0); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         if (rep >= 2 && ms < best) best = ms;
