@@ -102,6 +102,7 @@ __device__ __forceinline__ float iou_boxc(const BoxC& a, const BoxC& b)
     const float ox = (0.0f < dx) ? dx : 0.0f;
     const float oy = (0.0f < dy) ? dy : 0.0f;
     const float inter = ox * oy;
+    if (!(inter > 0.0f)) return 0.0f;           // disjoint (or touching) boxes: 0 / uni = 0 (and uni <= 0 gives 0 too): no divide for the lanes -- most pairs of a crowd
     const float uni = a.area + b.area - inter;
     return (uni > 0) ? inter / uni : 0.0f;
 }
@@ -147,55 +148,84 @@ __device__ __forceinline__ void write_det(zly_det* dst, const Cand& c)
 __device__ __forceinline__ float rl_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 __device__ __forceinline__ int rl_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 
+#ifdef ZLY_NMS_DIAG
+__device__ unsigned long long* g_nms_diag = nullptr;             // diagnostic build only (tools/nms_bench.hip): cycle stamps of the general path, frame 0
+#define NMSSTAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && g_nms_diag) g_nms_diag[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define NMSSTAMP(k) do { } while (0)
+#endif
+
 // general path: rank sort over the whole frame + per-class greedy loop with removed flags in memory
 // keys: the sort keys of the frame's candidates staged in LDS (class | confidence | anchor; nullptr when they do not fit): the rank loop
 // compares every candidate with every other one, and reading the others from global memory -- 600 dependent L2 round trips per thread for the
 // 600 candidates of a crowded frame -- was 0.77 ms of a 2.4 ms YOLOv8-s 640 x 640 step (profiles/r03_bench_yolov8s_640_b32.json)
-__device__ void nms_general(const Cand* gsrc, int n, float iou_thr, int nc, Cand* sorted, bool in_lds, int* keys, int kcap,
+__device__ void nms_general(const Cand* gsrc, int n, float iou_thr, int nc, Cand* sorted, bool in_lds, int* keys, int kcap, unsigned long long* rows,
                             int* seg_start, int* seg_end, int* wave_tot, int* run_base, zly_det* dets, int cap, int* n_kept_out)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    NMSSTAMP(0);
     for (int c = tid; c < nc; c += NMS_THREADS) { seg_start[c] = -1; seg_end[c] = -1; }
     if (tid == 0) *run_base = 0;
-    const int n4 = (n + 3) & ~3;
     if (keys) {
-        for (int i = tid; i < n4; i += NMS_THREADS) {
-            Cand c;
-            if (i < n) c = gsrc[i];
-            else { c.cls = 0x7fffffff; c.conf = 0.f; c.anchor = 0x7fffffff; }          // padding: sorts behind every real candidate
-            keys[i] = c.cls; keys[kcap + i] = __float_as_int(c.conf); keys[2 * kcap + i] = c.anchor;
+        // Bitonic sort of (class asc | confidence desc | anchor asc | source index) in LDS: the order is strict (anchors are unique), so any
+        // correct sort gives the reference's order.  (The rank sort it replaces compared every candidate with every other one: 255 k cycles
+        // for 600 candidates, 700 k for 850 -- half of a crowded frame's NMS; profiles/r03_nms_general_path_stamps.txt.)
+        int n2 = 1;
+        while (n2 < n) n2 <<= 1;
+        // two 64-bit words per candidate: k1 = class | ~confidence bits (confidences are positive floats: their bit patterns order like the
+        // values, so ascending k1 = class asc, confidence desc), k2 = anchor | source index
+        unsigned long long* k1 = reinterpret_cast<unsigned long long*>(keys);
+        unsigned long long* k2 = k1 + kcap;
+        for (int i = tid; i < n2; i += NMS_THREADS) {
+            if (i < n) {
+                const Cand c = gsrc[i];
+                k1[i] = ((unsigned long long)(unsigned)c.cls << 32) | (unsigned long long)(~(unsigned)__float_as_int(c.conf));
+                k2[i] = ((unsigned long long)(unsigned)c.anchor << 32) | (unsigned long long)(unsigned)i;
+            } else { k1[i] = ~0ull; k2[i] = ~0ull; }                         // padding: behind every real candidate
         }
-    }
-    __syncthreads();
-    for (int i = tid; i < n; i += NMS_THREADS) {
-        const Cand ci = gsrc[i];
-        int rank = 0;
-        if (keys) {
-            typedef __attribute__((ext_vector_type(4))) int i32x4;
-            for (int j = 0; j < n4; j += 4) {                        // four candidates per step: three 16-byte broadcast reads
-                const i32x4 kc = *reinterpret_cast<const i32x4*>(keys + j);
-                const i32x4 kf = *reinterpret_cast<const i32x4*>(keys + kcap + j);
-                const i32x4 ka = *reinterpret_cast<const i32x4*>(keys + 2 * kcap + j);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    Cand o;
-                    o.cls = kc[k]; o.conf = __int_as_float(kf[k]); o.anchor = ka[k];
-                    rank += cand_before(o, ci) ? 1 : 0;
+        __syncthreads();
+        NMSSTAMP(1);
+        // pass (k, j): compare-exchange pairs (t, t | j), one pair per thread-iteration.  A wave's 64 pairs of a pass with j <= 64 lie inside
+        // ITS 128 elements, so those passes (49 of the 55 for 1024 elements) are ordered by a wave barrier; only strides above 64 cross waves
+        const int np = n2 >> 1;
+        for (int k = 2; k <= n2; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int pp = tid; pp < np; pp += NMS_THREADS) {
+                    const int t = ((pp & ~(j - 1)) << 1) | (pp & (j - 1)), u = t | j;
+                    const unsigned long long a1 = k1[t], a2 = k2[t], b1 = k1[u], b2 = k2[u];
+                    const bool a_first = a1 < b1 || (a1 == b1 && a2 < b2);
+                    const bool asc = (t & k) == 0;
+                    if (asc != a_first && !(a1 == b1 && a2 == b2)) { k1[t] = b1; k2[t] = b2; k1[u] = a1; k2[u] = a2; }
+                }
+                if (j > 64 || (j == 1 && k >= 128)) __syncthreads();
+                else {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 }
             }
-        } else {
+        __syncthreads();
+        for (int i = tid; i < n; i += NMS_THREADS) sorted[i] = gsrc[(unsigned)(k2[i] & 0xffffffffull)];
+    } else {
+        __syncthreads();
+        NMSSTAMP(1);
+        for (int i = tid; i < n; i += NMS_THREADS) {
+            const Cand ci = gsrc[i];
+            int rank = 0;
             for (int j = 0; j < n; ++j) rank += cand_before(gsrc[j], ci) ? 1 : 0;
+            sorted[rank] = ci;
         }
-        sorted[rank] = ci;
     }
     if (!in_lds) __threadfence();
     __syncthreads();
+    NMSSTAMP(2);
     for (int i = tid; i < n; i += NMS_THREADS) {
         const int c = sorted[i].cls;
         if (i == 0 || sorted[i - 1].cls != c) seg_start[c] = i;
         if (i == n - 1 || sorted[i + 1].cls != c) seg_end[c] = i + 1;
     }
     __syncthreads();
+    NMSSTAMP(3);
     // Crowded classes (more than NMS_BIG_CLASS candidates) are resolved by the WHOLE workgroup in blocks of 64 sorted candidates: (1) one wave
     // runs the greedy loop among the block's members in registers (their flags already carry the suppressions of earlier blocks); (2) all
     // threads test the candidates behind the block against the block's survivors.  Every candidate's fate is decided by the kept boxes in
@@ -205,24 +235,39 @@ __device__ void nms_general(const Cand* gsrc, int n, float iou_thr, int nc, Cand
         const int s = seg_start[c], e = seg_end[c];                        // workgroup-uniform
         if (s < 0 || e - s <= NMS_BIG_CLASS) continue;
         for (int i0 = s; i0 < e; i0 += 64) {
-            if (wave == 0) {
+            // (1a) the block's 64 x 64 "suppresses" matrix, all waves: lane j holds member j, wave w evaluates rows 8 w .. 8 w + 7 (row i, bit j:
+            //      j > i and IoU(member i, member j) > thr: pure geometry, one __ballot per row).  (1b) wave 0 then runs the greedy loop over
+            //      the members on the row masks alone -- bit operations, where it used to evaluate an IoU with an IEEE divide per kept member.
+            {
                 const int idx = i0 + lane;
                 const bool valid = idx < e;
                 Cand me;
                 if (valid) me = sorted[idx];
                 else { me.x = me.y = me.w = me.h = 0.f; me.conf = 0.f; me.cls = c; me.anchor = 0; me.pad_ = 1; }
-                unsigned long long alive = __ballot(valid && me.pad_ == 0);
-                const int nb = min(64, e - i0);
                 const BoxC mc = boxc(me);
-                for (int i = 0; i < nb - 1; ++i) {
-                    if (!((alive >> i) & 1ull)) continue;                  // wave-uniform
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const int i = wave * 8 + r;                            // wave-uniform row
                     BoxC bi;
                     bi.x0 = rl_f(mc.x0, i); bi.y0 = rl_f(mc.y0, i); bi.x1 = rl_f(mc.x1, i); bi.y1 = rl_f(mc.y1, i); bi.area = rl_f(mc.area, i);
-                    const bool kill = lane > i && ((alive >> lane) & 1ull) && iou_boxc(bi, mc) > iou_thr;
-                    alive &= ~__ballot(kill);
+                    const bool sup = valid && lane > i && i0 + i < e && iou_boxc(bi, mc) > iou_thr;
+                    const unsigned long long row = __ballot(sup);
+                    if (lane == 0) rows[i] = row;
                 }
-                if (valid && me.pad_ == 0 && !((alive >> lane) & 1ull)) sorted[idx].pad_ = 1;
-                if (lane == 0) { wave_tot[0] = (int)(alive & 0xffffffffull); wave_tot[1] = (int)(alive >> 32); }
+                __syncthreads();
+                if (wave == 0) {
+                    unsigned long long alive = __ballot(valid && me.pad_ == 0);
+                    const unsigned long long myrow = rows[lane];
+                    const int rlo = (int)(myrow & 0xffffffffull), rhi = (int)(myrow >> 32);
+                    const int nb = min(64, e - i0);
+                    for (int i = 0; i < nb - 1; ++i) {
+                        if (!((alive >> i) & 1ull)) continue;              // wave-uniform
+                        const unsigned long long ri = ((unsigned long long)(unsigned)rl_i(rhi, i) << 32) | (unsigned long long)(unsigned)rl_i(rlo, i);
+                        alive &= ~ri;
+                    }
+                    if (valid && me.pad_ == 0 && !((alive >> lane) & 1ull)) sorted[idx].pad_ = 1;
+                    if (lane == 0) { wave_tot[0] = (int)(alive & 0xffffffffull); wave_tot[1] = (int)(alive >> 32); }
+                }
             }
             if (!in_lds) __threadfence();
             __syncthreads();
@@ -251,6 +296,7 @@ __device__ void nms_general(const Cand* gsrc, int n, float iou_thr, int nc, Cand
             __syncthreads();
         }
     }
+    NMSSTAMP(4);
     if (n > 1) {
         for (int c = wave; c < nc; c += NMS_WAVES) {
             const int s = seg_start[c], e = seg_end[c];
@@ -270,6 +316,7 @@ __device__ void nms_general(const Cand* gsrc, int n, float iou_thr, int nc, Cand
     }
     if (!in_lds) __threadfence();
     __syncthreads();
+    NMSSTAMP(5);
     for (int i0 = 0; i0 < n; i0 += NMS_THREADS) {
         const int i = i0 + tid;
         const bool keep = (i < n) && (sorted[i].pad_ == 0);
@@ -291,6 +338,7 @@ __device__ void nms_general(const Cand* gsrc, int n, float iou_thr, int nc, Cand
         __syncthreads();
     }
     if (tid == 0) *n_kept_out = *run_base;
+    NMSSTAMP(6);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -399,12 +447,13 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const Cand* __restrict
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char nms_dyn[];
     Cand* lds_c = reinterpret_cast<Cand*>(nms_dyn);                                  // [CAP] class-bucketed candidates (general path: sorted list)
-    int* lds_keys = reinterpret_cast<int*>(nms_dyn + (size_t)CAP * sizeof(Cand));     // [3 * CAP] general path: sort keys (class | confidence bits | anchor)
+    int* lds_keys = reinterpret_cast<int*>(nms_dyn + (size_t)CAP * sizeof(Cand));     // [4 * CAP] general path: sort keys (class | confidence bits | anchor | source index)
     __shared__ int cls_cnt[NMS_MAX_CLASSES];      // candidates per class -> later: kept per class
     __shared__ int cls_off[NMS_MAX_CLASSES];      // segment start per class
     __shared__ int cls_fill[NMS_MAX_CLASSES];     // scatter cursor / general path seg_end
     __shared__ int wave_tot[NMS_WAVES];
     __shared__ int sh_misc[4];                    // [0] max class count, [1] run_base, [2] n_kept
+    __shared__ unsigned long long nms_rows[64];   // general path, crowded classes: the current block's suppression matrix
 
     const int f = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -465,7 +514,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const Cand* __restrict
         // general path (uniform per workgroup)
         const bool in_lds = n <= CAP;
         __syncthreads();
-        nms_general(gsrc, n, iou_thr, nc, in_lds ? lds_c : scratch_all + (size_t)f * N, in_lds, in_lds ? lds_keys : nullptr, CAP,
+        nms_general(gsrc, n, iou_thr, nc, in_lds ? lds_c : scratch_all + (size_t)f * N, in_lds, in_lds ? lds_keys : nullptr, CAP, nms_rows,
                     cls_off, cls_fill, wave_tot, &sh_misc[1], dets, cap, &sh_misc[2]);
         __syncthreads();
         if (tid == 0) {
@@ -558,7 +607,7 @@ static bool g_nms_big_ok = false;
 hipError_t nms_init()
 {
     g_nms_big_ok = hipFuncSetAttribute((const void*)nms_kernel<2 * NMS_LDS_CAP>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        2 * NMS_LDS_CAP * (int)(sizeof(Cand) + 12)) == hipSuccess;
+                                        2 * NMS_LDS_CAP * (int)(sizeof(Cand) + 16)) == hipSuccess;
     return hipSuccess;
 }
 
@@ -568,10 +617,10 @@ hipError_t launch_nms(const Cand* cand, int* cand_count, int N, int n, float iou
     if (nc > NMS_MAX_CLASSES) return hipErrorInvalidValue;
     static const int force_general = getenv("ZLY_NMS_GENERAL") != nullptr ? 1 : 0;     // tests / A-B: every frame on the eight-wave path
     if (N > 4096 && g_nms_big_ok)
-        hipLaunchKernelGGL(nms_kernel<2 * NMS_LDS_CAP>, dim3(n), dim3(NMS_THREADS), (size_t)2 * NMS_LDS_CAP * (sizeof(Cand) + 12), s, cand, cand_count, N, iou_thr, nc,
+        hipLaunchKernelGGL(nms_kernel<2 * NMS_LDS_CAP>, dim3(n), dim3(NMS_THREADS), (size_t)2 * NMS_LDS_CAP * (sizeof(Cand) + 16), s, cand, cand_count, N, iou_thr, nc,
                            scratch, (unsigned char*)slabs, cap, tag0, force_general);
     else
-        hipLaunchKernelGGL(nms_kernel<NMS_LDS_CAP>, dim3(n), dim3(NMS_THREADS), (size_t)NMS_LDS_CAP * (sizeof(Cand) + 12), s, cand, cand_count, N, iou_thr, nc,
+        hipLaunchKernelGGL(nms_kernel<NMS_LDS_CAP>, dim3(n), dim3(NMS_THREADS), (size_t)NMS_LDS_CAP * (sizeof(Cand) + 16), s, cand, cand_count, N, iou_thr, nc,
                            scratch, (unsigned char*)slabs, cap, tag0, force_general);
     return hipGetLastError();
 }

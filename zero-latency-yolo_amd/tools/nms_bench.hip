@@ -7,6 +7,9 @@
 #include <random>
 using namespace zly;
 
+#ifdef ZLY_NMS_DIAG
+static unsigned long long* g_dbg = nullptr;
+#endif
 static void run(const char* name, int frames, int n, int big_class_share_pct, int nc, float spread)
 {
     const int N = 8400, cap = 1024;
@@ -38,12 +41,24 @@ static void run(const char* name, int frames, int n, int big_class_share_pct, in
         if (rep >= 2 && ms < best) best = ms;
     }
     zly_slab_header hd; hipMemcpy(&hd, slabs, sizeof hd, hipMemcpyDeviceToHost);
+#ifdef ZLY_NMS_DIAG
+    {
+        unsigned long long h7[8] = {0}; hipMemcpy(h7, g_dbg, sizeof h7, hipMemcpyDeviceToHost);
+        if (h7[6] > h7[0]) printf("      general path, frame 0, cycles: key staging %llu | rank sort %llu | class bounds %llu | crowded classes %llu | other classes %llu | compaction %llu\n",
+                                  h7[1] - h7[0], h7[2] - h7[1], h7[3] - h7[2], h7[4] - h7[3], h7[5] - h7[4], h7[6] - h7[5]);
+        hipMemset(g_dbg, 0, 64);
+    }
+#endif
     printf("%-44s %2d frames x %4d candidates, %3d %% in one class: %8.1f us   (frame 0 kept %d)\n", name, frames, n, big_class_share_pct, best * 1e3, hd.n_kept);
     hipFree(d); hipFree(scratch); hipFree(dc); hipFree(slabs);
 }
 
 int main()
 {
+#ifdef ZLY_NMS_DIAG
+    hipMalloc((void**)&g_dbg, 64); hipMemset(g_dbg, 0, 64);
+    hipMemcpyToSymbol(HIP_SYMBOL(g_nms_diag), &g_dbg, sizeof g_dbg);
+#endif
     run("one-wave path", 32, 100, 20, 80, 1.0f);
     run("class segments in registers (all <= 64)", 32, 600, 0, 80, 1.0f);
     run("crowded class, sparse boxes", 32, 600, 90, 80, 1.0f);
