@@ -856,7 +856,7 @@ struct WsGeom { int TH, TW, tiles_x, tiles_y, total_tiles, pitch, nchunks, nwc, 
 __device__ unsigned long long* g_ws_diag = nullptr;              // diagnostic build only (tools/ws_bench.hip): per-wave phase cycle sums
 #endif
 
-template <int TPW, int NKS>
+template <int TPW, int NKS, bool RES>
 __global__ __launch_bounds__(256, 2) void conv3x3_ws_kernel(const ConvArgs a, const WsGeom g)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -895,6 +895,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ws_kernel(const ConvArgs a, co
     const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (unsigned)((size_t)a.M * a.out_cs * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.res ? a.res : a.out), 0,
                                                                           (unsigned)((size_t)a.M * (a.res ? a.res_cs : a.out_cs) * 2), 0x00020000);
+    // this lane's first output channel: TPW = 2 -> a pair of tiles (pair-permuted rows): 8 consecutive channels; TPW = 1 -> 4 channels of tile wc
+    const int ch0 = TPW == 2 ? wc * 32 + kq * 8 : wc * 16 + kq * 4;
+    const bool act = a.act != 0;
+    constexpr bool has_res = RES;                            // a template parameter: a run-time test would split the block the epilogue shares with the next pair's MFMAs
     // tap offsets of the k-steps inside the patch (wave-uniform): k-step s = tap * nchunks + chunk
     int toff[NKS];
 #pragma unroll
@@ -949,20 +953,26 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ws_kernel(const ConvArgs a, co
         __syncthreads();                                        // everybody's have
         WSPHASE(0);
         // ---- this wave's column tiles: wp, wp + nwp, ... two at a time (independent accumulators and fragment streams: a lone wave per
-        //      workgroup and SIMD has nothing else to cover the ds_read latency and the previous pair's epilogue with) ----------------------
-        for (int t0 = wp; t0 < nct; t0 += 2 * g.nwp) {
-            const unsigned char* px[2];
-            int qq[2], gyy[2], gxx[2];
+        //      workgroup and SIMD has nothing else to cover the ds_read latency with).  The loop is software-pipelined by one pair: the
+        //      epilogue of pair k (bias + SiLU + convert: ~150 VALU instructions, the larger half of a pair's time in the stamped build)
+        //      stands in the same straight-line block as the 36-72 MFMAs of pair k + 1 -- no branch in between: lanes without a pixel store
+        //      to an out-of-range offset -- so the matrix and the vector pipe work at the same time instead of one after the other. ----------------------
+        auto pair_setup = [&](int t0, const unsigned char* (&px)[2], int (&ob)[2], int (&rb)[2]) {
 #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2) {
                 const int t = min(t0 + h2 * g.nwp, nct - 1);
-                qq[h2] = (t0 + h2 * g.nwp < nct) ? t * 16 + p : NPB;              // a missing second tile: computed on a copy of the last, never stored
-                const int qc = min(t * 16 + p, NPB - 1);
+                const int q = t * 16 + p;
+                const int qc = min(q, NPB - 1);
                 const int oy = (int)(((float)qc + 0.5f) * invTW), ox = qc - oy * g.TW;
                 px[h2] = cur + (oy * PW + ox) * g.pitch + kq * 16;
-                gyy[h2] = y0 + oy; gxx[h2] = x0 + ox;
+                const int gy = y0 + oy, gx = x0 + ox;
+                const bool ok = (t0 + h2 * g.nwp < nct) && q < NPB && gy < a.Ho && gx < a.Wo;       // a missing second tile: computed on a copy of the last, never stored
+                const int m = (b * a.Ho + gy) * a.Wo + gx;
+                ob[h2] = ok ? (m * a.out_cs + a.out_co + ch0) * 2 : (int)0x80000000;
+                rb[h2] = ok ? (m * a.res_cs + a.res_co + ch0) * 2 : (int)0x80000000;
             }
-            f32x4 acc[2][TPW];
+        };
+        auto pair_mma = [&](const unsigned char* const (&px)[2], f32x4 (&acc)[2][TPW]) {
 #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
@@ -984,10 +994,62 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ws_kernel(const ConvArgs a, co
                     acc[1][c] = mma_step(w[c][s], xf[1][s % (WS_DEPTH + 1)], acc[1][c]);
                 }
             }
+        };
+        auto pair_store = [&](const f32x4 (&acc)[2][TPW], const int (&ob)[2], const int (&rb)[2]) {
 #pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2)
-                if (qq[h2] < NPB && gyy[h2] < a.Ho && gxx[h2] < a.Wo)
-                    epilogue_px_buf<TPW>(a, rout, rres, acc[h2], biasr, wc * TPW, kq, (b * a.Ho + gyy[h2]) * a.Wo + gxx[h2]);
+            for (int h2 = 0; h2 < 2; ++h2) {
+                f32x4 o[TPW];
+#pragma unroll
+                for (int c = 0; c < TPW; ++c) {
+                    o[c] = acc[h2][c] + biasr[c];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[c][r] = act ? silu<bf16_t>(o[c][r]) : o[c][r];
+                }
+                if (TPW == 2) {
+                    f32x4 lo = o[0], hi = o[TPW - 1];
+                    if (has_res) {                              // wave-uniform
+                        const bf16x8 r = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rres, rb[h2], 0, 0));
+                        lo += f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
+                        hi += f32x4{(float)r[4], (float)r[5], (float)r[6], (float)r[7]};
+                    }
+                    bf16x8 wv;
+                    wv[0] = (bf16_t)lo[0]; wv[1] = (bf16_t)lo[1]; wv[2] = (bf16_t)lo[2]; wv[3] = (bf16_t)lo[3];
+                    wv[4] = (bf16_t)hi[0]; wv[5] = (bf16_t)hi[1]; wv[6] = (bf16_t)hi[2]; wv[7] = (bf16_t)hi[3];
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, wv), rout, ob[h2], 0, 0);
+                } else {
+                    f32x4 x = o[0];
+                    if (has_res) {
+                        const bf16x4 r = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(rres, rb[h2], 0, 0));
+                        x += f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
+                    }
+                    bf16x4 wv;
+                    wv[0] = (bf16_t)x[0]; wv[1] = (bf16_t)x[1]; wv[2] = (bf16_t)x[2]; wv[3] = (bf16_t)x[3];
+                    typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, wv), rout, ob[h2], 0, 0);
+                }
+            }
+        };
+        if (wp < nct) {
+            const unsigned char* pxa[2];
+            int oba[2], rba[2];
+            f32x4 acca[2][TPW];
+            pair_setup(wp, pxa, oba, rba);
+            pair_mma(pxa, acca);
+            for (int t0 = wp + 2 * g.nwp; t0 < nct; t0 += 2 * g.nwp) {
+                const unsigned char* pxb[2];
+                int obb[2], rbb[2];
+                f32x4 accb[2][TPW];
+                pair_setup(t0, pxb, obb, rbb);
+                pair_store(acca, oba, rba);                     // epilogue of the previous pair ...
+                pair_mma(pxb, accb);                            // ... beside the MFMAs of this one
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    oba[h2] = obb[h2]; rba[h2] = rbb[h2];
+#pragma unroll
+                    for (int c = 0; c < TPW; ++c) acca[h2][c] = accb[h2][c];
+                }
+            }
+            pair_store(acca, oba, rba);
         }
         WSPHASE(2);
         if (tl + (int)gridDim.x < g.total_tiles) {
@@ -1006,10 +1068,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ws_kernel(const ConvArgs a, co
 }
 
 typedef void (*conv_ws_fn)(const ConvArgs, const WsGeom);
-static conv_ws_fn pick_ws(int cin, int tpw)
+static conv_ws_fn pick_ws(int cin, int tpw, bool res = false)
 {
     if (cin != 64) return nullptr;
-    return tpw == 2 ? conv3x3_ws_kernel<2, 18> : conv3x3_ws_kernel<1, 18>;
+    if (res) return tpw == 2 ? conv3x3_ws_kernel<2, 18, true> : conv3x3_ws_kernel<1, 18, true>;
+    return tpw == 2 ? conv3x3_ws_kernel<2, 18, false> : conv3x3_ws_kernel<1, 18, false>;
 }
 static constexpr int WS_LDS_MAX = 64 * 1024;        // two resident workgroups per CU with room to spare (two of exactly 80 KB did not both become resident)
 
@@ -1037,9 +1100,12 @@ static bool ws_plan(int H, int W, int cin, int n, WsGeom* g)
 
 hipError_t ws_init()
 {
-    hipError_t r = hipFuncSetAttribute((const void*)pick_ws(64, 2), hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_MAX);
-    if (r != hipSuccess) return r;
-    return hipFuncSetAttribute((const void*)pick_ws(64, 1), hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_MAX);
+    for (int tpw = 1; tpw <= 2; ++tpw)
+        for (int res = 0; res <= 1; ++res) {
+            hipError_t r = hipFuncSetAttribute((const void*)pick_ws(64, tpw, res != 0), hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_MAX);
+            if (r != hipSuccess) return r;
+        }
+    return hipSuccess;
 }
 
 static int g_num_cus = 256;
@@ -1232,7 +1298,7 @@ hipError_t launch_conv(int dtype, const ConvArgs& a, const ConvLaunch& cfg, hipS
         m.cout_pad = even * 16;
         m.Cout = a.Cout < even * 16 ? a.Cout : even * 16;
         g.nwc = even / 2; g.nwp = 4 / g.nwc;
-        hipLaunchKernelGGL(pick_ws(a.Cin, 2), dim3(gx), dim3(256), lds, s, m, g);
+        hipLaunchKernelGGL(pick_ws(a.Cin, 2, a.res != nullptr), dim3(gx), dim3(256), lds, s, m, g);
         if (ntiles > even && a.Cout > even * 16) {
             // the odd last tile (pair-permuted rows cover the even tiles only, so it is a plain 16-channel conv of its own): 1 x 4 waves
             ConvArgs r = a;
@@ -1242,7 +1308,7 @@ hipError_t launch_conv(int dtype, const ConvArgs& a, const ConvLaunch& cfg, hipS
             if (a.res) r.res_co = a.res_co + even * 16;
             r.Cout = a.Cout - even * 16; r.cout_pad = 16;
             g.nwc = 1; g.nwp = 4;
-            hipLaunchKernelGGL(pick_ws(a.Cin, 1), dim3(gx), dim3(256), lds, s, r, g);
+            hipLaunchKernelGGL(pick_ws(a.Cin, 1, a.res != nullptr), dim3(gx), dim3(256), lds, s, r, g);
         }
         return hipGetLastError();
     }
