@@ -19,6 +19,7 @@
 // 16-wide k-step so that both operands still arrive as 16-byte loads.
 #include "zly_internal.h"
 #include "conv_device.h"
+#include <type_traits>
 
 namespace zly {
 
@@ -856,7 +857,7 @@ struct WsGeom { int TH, TW, tiles_x, tiles_y, total_tiles, pitch, nchunks, nwc, 
 __device__ unsigned long long* g_ws_diag = nullptr;              // diagnostic build only (tools/ws_bench.hip): per-wave phase cycle sums
 #endif
 
-template <int TPW, int NKS, bool RES>
+template <int TPW, int NKS, bool RES, bool ROWT = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_ws_kernel(const ConvArgs a, const WsGeom g)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -876,7 +877,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ws_kernel(const ConvArgs a, co
     const int upp = a.Cin >> 3;                                 // 16-byte units per patch pixel
     const int NPU = PH * PW * upp;
     const float inv_upp = 1.0f / (float)upp, invPW = 1.0f / (float)PW, invTW = 1.0f / (float)g.TW;
-    const int NPB = g.TH * g.TW, nct = (NPB + 15) >> 4;          // pixels / 16-pixel column tiles of a tile
+    const int NPB = g.TH * g.TW, nct = ROWT ? g.TH : (NPB + 15) >> 4;          // pixels / 16-pixel column tiles of a tile (ROWT: one tile per row)
     const int tiles_per_img = g.tiles_x * g.tiles_y;
 
     // ---- this wave's weights: tiles wc * TPW .. + TPW - 1, every k-step, resident in registers for the workgroup's lifetime ----
@@ -961,9 +962,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ws_kernel(const ConvArgs a, co
 #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2) {
                 const int t = min(t0 + h2 * g.nwp, nct - 1);
-                const int q = t * 16 + p;
+                const int q = ROWT ? (p < g.TW ? t * g.TW + p : NPB) : t * 16 + p;
                 const int qc = min(q, NPB - 1);
-                const int oy = (int)(((float)qc + 0.5f) * invTW), ox = qc - oy * g.TW;
+                const int oy = ROWT ? t : (int)(((float)qc + 0.5f) * invTW), ox = ROWT ? p : qc - oy * g.TW;     // ROWT: lanes beyond the row read patch columns that exist (row pitch TW + 8) and store nothing
                 px[h2] = cur + (oy * PW + ox) * g.pitch + kq * 16;
                 const int gy = y0 + oy, gx = x0 + ox;
                 const bool ok = (t0 + h2 * g.nwp < nct) && q < NPB && gy < a.Ho && gx < a.Wo;       // a missing second tile: computed on a copy of the last, never stored
@@ -977,6 +978,46 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ws_kernel(const ConvArgs a, co
             for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
                 for (int c = 0; c < TPW; ++c) acc[h2][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (ROWT) {
+                // One tile = one output ROW (TW + 2 <= 16): lane p reads patch column p of row r + ky ONCE per 32-channel chunk; the fragments
+                // of the taps kx = 1, 2 are that of lanes p + 1, p + 2 -- two DPP row shifts instead of two more LDS reads.  With 2 channel tiles
+                // per wave the linearised form asks the LDS for 1 KiB per 2 MFMAs (256 B/cycle per CU against the 128 it delivers: the matrix
+                // pipe cannot exceed ~50 %); this form needs a third of that, for 13 row tiles instead of 11 column tiles per 13 x 13 tile.
+                static_assert(!ROWT || NKS == 18, "row tiles: Cin = 64");
+                bf16x8 xr[2][6];
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int ck = 0; ck < 2; ++ck) xr[h2][ky * 2 + ck] = *reinterpret_cast<const bf16x8*>(px[h2] + ky * PW * g.pitch + ck * 64);
+                auto shl = [](const bf16x8& v, auto ctrl) {
+                    const u32x4 u = __builtin_bit_cast(u32x4, v);
+                    u32x4 r;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) r[k] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)u[k], decltype(ctrl)::value, 0xf, 0xf, false);
+                    return __builtin_bit_cast(bf16x8, r);
+                };
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int ck = 0; ck < 2; ++ck) {
+                        bf16x8 f[2][3];
+#pragma unroll
+                        for (int h2 = 0; h2 < 2; ++h2) {
+                            f[h2][0] = xr[h2][ky * 2 + ck];
+                            f[h2][1] = shl(f[h2][0], std::integral_constant<int, 0x101>{});      // row_shl:1 -- lane p <- lane p + 1
+                            f[h2][2] = shl(f[h2][0], std::integral_constant<int, 0x102>{});      // row_shl:2
+                        }
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                            for (int c = 0; c < TPW; ++c)
+#pragma unroll
+                                for (int h2 = 0; h2 < 2; ++h2) acc[h2][c] = mma_step(w[c][(ky * 3 + kx) * 2 + ck], f[h2][kx], acc[h2][c]);
+                    }
+                return;
+            }
             // pixel fragments are read WS_DEPTH k-steps ahead of the MFMAs that consume them (statically indexed rings)
             constexpr int WS_DEPTH = 3;
             bf16x8 xf[2][WS_DEPTH + 1];
@@ -1068,9 +1109,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ws_kernel(const ConvArgs a, co
 }
 
 typedef void (*conv_ws_fn)(const ConvArgs, const WsGeom);
-static conv_ws_fn pick_ws(int cin, int tpw, bool res = false)
+static conv_ws_fn pick_ws(int cin, int tpw, bool res = false, bool rowt = false)
 {
     if (cin != 64) return nullptr;
+    if (rowt && tpw == 2) return res ? conv3x3_ws_kernel<2, 18, true, true> : conv3x3_ws_kernel<2, 18, false, true>;
     if (res) return tpw == 2 ? conv3x3_ws_kernel<2, 18, true> : conv3x3_ws_kernel<1, 18, true>;
     return tpw == 2 ? conv3x3_ws_kernel<2, 18, false> : conv3x3_ws_kernel<1, 18, false>;
 }
@@ -1101,10 +1143,11 @@ static bool ws_plan(int H, int W, int cin, int n, WsGeom* g)
 hipError_t ws_init()
 {
     for (int tpw = 1; tpw <= 2; ++tpw)
-        for (int res = 0; res <= 1; ++res) {
-            hipError_t r = hipFuncSetAttribute((const void*)pick_ws(64, tpw, res != 0), hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_MAX);
-            if (r != hipSuccess) return r;
-        }
+        for (int res = 0; res <= 1; ++res)
+            for (int rowt = 0; rowt <= 1; ++rowt) {
+                hipError_t r = hipFuncSetAttribute((const void*)pick_ws(64, tpw, res != 0, rowt != 0), hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_MAX);
+                if (r != hipSuccess) return r;
+            }
     return hipSuccess;
 }
 
@@ -1298,7 +1341,8 @@ hipError_t launch_conv(int dtype, const ConvArgs& a, const ConvLaunch& cfg, hipS
         m.cout_pad = even * 16;
         m.Cout = a.Cout < even * 16 ? a.Cout : even * 16;
         g.nwc = even / 2; g.nwp = 4 / g.nwc;
-        hipLaunchKernelGGL(pick_ws(a.Cin, 2, a.res != nullptr), dim3(gx), dim3(256), lds, s, m, g);
+        static const bool rowt_env = getenv("ZLY_WS_ROWT") != nullptr;            // experiment: one MFMA tile per output row, kx taps by DPP shifts
+        hipLaunchKernelGGL(pick_ws(a.Cin, 2, a.res != nullptr, rowt_env && g.TW + 2 <= 16), dim3(gx), dim3(256), lds, s, m, g);
         if (ntiles > even && a.Cout > even * 16) {
             // the odd last tile (pair-permuted rows cover the even tiles only, so it is a plain 16-channel conv of its own): 1 x 4 waves
             ConvArgs r = a;
