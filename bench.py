@@ -474,8 +474,14 @@ def run():
         eng.detect_device(sets_b[last % len(sets_b)].data_ptr(), B, a.size, a.size, d_slabs_ptr=ref_slab.data_ptr(), tag0=last * B, stream=sp if n_eng == 1 else 0)
         eng.join(sp)
         torch.cuda.synchronize()
-        mine = gb_head[last % 2].view(world, B * sb)[rank]
-        assert torch.equal(mine, ref_slab), "gathered slabs of the last step differ from a single-engine run on the same frames"
+        mine = gb_head[last % 2].view(world, B * sb)[rank].view(B, sb).cpu().numpy()
+        want = ref_slab.view(B, sb).cpu().numpy()
+        cap_d = (sb - 16) // 40
+        for f in range(B):
+            # a slab = 16-byte header + cap detections of which the first n_kept are written: the bytes behind them are whatever an earlier
+            # step left in the ring buffer, so the comparison covers the header and the written detections
+            nk = min(int(want[f, :4].view(np.int32)[0]), cap_d)
+            assert np.array_equal(mine[f, :16 + 40 * nk], want[f, :16 + 40 * nk]), f"gathered slab of frame {f} of the last step differs from a single-engine run on the same frames"
         result["gather"] = {"ranks": world, "bytes_per_rank_per_step": B * sb, "frames_checked": int(hd.shape[0]), "equals_single_engine_run": True}
         dist.barrier()
     if rank == 0 and world == 1 and not a.no_extras and default_cfg and os.environ.get("ZLY_BENCH_NO_H2H") != "1":
