@@ -455,6 +455,7 @@ static conv_stream_fn pick_stream(int ct, int pt, int nk)
     ZLY_STREAM_CASE(2, 4, 1); ZLY_STREAM_CASE(2, 4, 2);
     ZLY_STREAM_CASE(4, 2, 1); ZLY_STREAM_CASE(4, 2, 2); ZLY_STREAM_CASE(4, 2, 3); ZLY_STREAM_CASE(4, 2, 4);
     ZLY_STREAM_CASE(2, 1, 6); ZLY_STREAM_CASE(2, 1, 8);
+    ZLY_STREAM_CASE(4, 1, 6); ZLY_STREAM_CASE(4, 1, 8);          // 64 channels per wave: the input is read twice instead of four times for 128 outputs
 #undef ZLY_STREAM_CASE
     return nullptr;
 }
@@ -1249,6 +1250,11 @@ static bool pick_stream_config(int cin, int cout_pad, int M, ConvLaunch* cfg)
     int ct = 0, pt = 0;
     if (nk <= 2 && ntiles == 2) { ct = 2; pt = 4; }
     else if (nk <= 4 && ntiles % 4 == 0) { ct = 4; pt = 2; }
+    // 192 / 256 input channels (round 3): 64 output channels per wave (CT = 4) -- with CT = 2 the four channel blocks of a 128-channel layer
+    // each read the whole input: model.12.cv2 17.7 -> 15.1 us, model.18.cv1 / cv2 16.7 -> 14.5.  256 input channels go to the direct kernel,
+    // which is faster still there (model.6.cv2 21.1 -> 16.9 us, model.8.cv1 15.3 -> 13.3).  ZLY_STREAM_CT2 restores the old shapes (tests).
+    else if (nk == 6 && ntiles % 4 == 0 && !getenv("ZLY_STREAM_CT2")) { ct = 4; pt = 1; }
+    else if (nk == 8 && !getenv("ZLY_STREAM_CT2")) return false;
     else if ((nk == 6 || nk == 8) && ntiles % 2 == 0) { ct = 2; pt = 1; }
     if (!ct || !pick_stream(ct, pt, nk)) return false;
     if (const char* mx = getenv("ZLY_STREAM_MAX_NK")) { if (nk > atoi(mx)) return false; }          // tuning aid
