@@ -1402,7 +1402,7 @@ hipError_t launch_conv(int dtype, const ConvArgs& a, const ConvLaunch& cfg, hipS
         const int ngroups = (a.M + 16 * cfg.pt - 1) / (16 * cfg.pt);
         int gx = (ngroups + 3) / 4;
         const char* sw = getenv("ZLY_STREAM_WGS");         // tuning / tests: total persistent workgroups (default ~4 per CU)
-        const int wgs = sw && atoi(sw) > 0 ? atoi(sw) : 4 * num_cus();
+        const int wgs = sw && atoi(sw) > 0 ? atoi(sw) : (cfg.ct == 4 && cfg.pt == 1 ? 2 : 4) * num_cus();      // the 64-channel shapes hold 2 workgroups per CU (189-239 VGPRs)
         const int cap = wgs / ytiles > 0 ? wgs / ytiles : 1;
         if (gx > cap) gx = cap;
         hipLaunchKernelGGL(sf, dim3(gx, ytiles, 1), dim3(256), 0, s, a, ngroups);
