@@ -332,7 +332,7 @@ def test_production_kernels_layerwise_vs_oracle(weights_path, oracle, ref_fp32, 
 @pytest.mark.parametrize("w,h,n,env", [(352, 288, 5, {}), (352, 288, 5, {"ZLY_NO_WRES": "1"}), (416, 416, 3, {"ZLY_STREAM_WGS": "8"}),
                                        (224, 416, 4, {"ZLY_LDS_WGS_PER_CU": "1"}), (416, 416, 3, {"ZLY_NO_WS": "1"}),
                                        (416, 416, 3, {"ZLY_C2F64": "1"}), (352, 288, 5, {"ZLY_C2F64": "1"}), (224, 416, 4, {"ZLY_C2F32_NW": "8"}),
-                                       (352, 288, 5, {"ZLY_C2F32_NW": "16"}), (416, 416, 3, {"ZLY_WS_ROWT": "1"}), (352, 288, 5, {"ZLY_STREAM_CT2": "1"})])
+                                       (352, 288, 5, {"ZLY_C2F32_NW": "16"}), (416, 416, 3, {"ZLY_WS_ROWT": "1"}), (352, 288, 5, {"ZLY_STREAM_CT2": "1"}), (416, 416, 3, {"ZLY_LDS_S2_PT1": "1"})])
 def test_throughput_kernels_on_ragged_maps(weights_path, oracle, monkeypatch, w, h, n, env):
     """conv3x3_lds_kernel, conv1x1_stream_kernel and bottleneck_pair_kernel forced onto small batches of ragged maps (88x72 ..
     11x9, 104x104 .. 13x13, 56x104 .. 7x13: partial tiles on every edge, 13-row maps, last pixel groups that are not full,

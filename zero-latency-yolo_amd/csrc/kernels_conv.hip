@@ -1231,7 +1231,9 @@ static bool pick_lds_config(int stride, int cin, int cout_pad, int n, int Ho, in
     }
     const int ytiles = ntiles / ct;
     const int tx = (Wo + 15) / 16;
-    int pt = stride == 1 ? 2 : 1;
+    // stride 2 (round 3): 8-row tiles where they still leave enough work items for the persistent grid (model.5 25.1 -> 21.6 us, model.7 23.6 -> 21.1;
+    // model.19's 256 items stay on 4-row tiles)
+    int pt = stride == 1 ? 2 : (((long)n * ((Wo + 15) / 16) * ((Ho + 7) / 8) * (ntiles / ct) >= 384 && !getenv("ZLY_LDS_S2_PT1")) ? 2 : 1);
     if (stride == 1 && ct == 2 && (long)n * tx * ((Ho + 15) / 16) * ytiles >= 2048) pt = 4;   // plenty of tiles, few channels: bigger tiles (VGPR budget)
     if (stride == 1 && Ho <= 14) pt = 1;                                            // 13-row maps: 4 x 4 rows
     if (ct == 5 && (pt > 1 || stride == 2)) { if (stride == 2) return false; pt = 1; }  // those variants do not fit 256 registers (2 waves per SIMD) without spilling
