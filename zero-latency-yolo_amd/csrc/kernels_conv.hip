@@ -1319,7 +1319,7 @@ void conv_pick_direct(int dtype, int ks, int cin, int cout_pad, int M, ConvLaunc
     const bool force_split = fk && nk >= atoi(fk);
     if (!force_split) {
         if (wgs_pt4 >= (e4 ? atol(e4) : 1024) && cfg->ct <= 4) { cfg->pt = 4; return; }       // CT=5 x PT=4 would need > 200 VGPRs
-        if (wgs_pt2 >= (e2 ? atol(e2) : 256)) { cfg->pt = 2; return; }                      // 1024 before: the K-heavy 1x1 layers at 26x26 re-read their weights per 16 pixels (+0.8 %)
+        if (wgs_pt2 >= (e2 ? atol(e2) : 512)) { cfg->pt = 2; return; }                      // 1024 before: the K-heavy 1x1 layers at 26x26 re-read their weights per 16 pixels (+0.8 %)
     }
     cfg->pt = 1;
     if (!force_split && (wgs_pt1 >= 512 || nk < 4)) return;
