@@ -145,6 +145,24 @@ def test_postprocess_crowded_class_blocks(eng16, oracle, n_one, n_other, box):
     assert n_cand == n and n_kept == len(want) and det_fields_equal(got, want)
 
 
+@pytest.mark.parametrize("n_one,n_other,box", [(700, 80, 14.0), (1500, 300, 10.0), (2040, 8, 8.0), (2300, 100, 12.0)])
+def test_postprocess_crowded_class_8400_anchors(eng16, oracle, n_one, n_other, box):
+    """The same on a head tensor of 8400 anchors (640 x 640 models): those get the NMS build that holds 2048 candidates per frame in LDS
+    (bitonic sort over 2048 keys, up to 32 blocks per class); 2300 candidates exceed it and take the global-memory path."""
+    rng = np.random.default_rng(2000 + n_one)
+    N = 8400
+    head = np.zeros((4 + 6, N), dtype=np.float32)
+    head[0] = rng.uniform(0, 640, N); head[1] = rng.uniform(0, 640, N)
+    head[2] = rng.uniform(box / 2, box, N); head[3] = rng.uniform(box / 2, box, N)
+    hot = rng.choice(N, n_one + n_other, replace=False)
+    head[4, hot[:n_one]] = rng.uniform(0.5, 1.0, n_one)
+    head[4, hot[:6]] = 0.625                                  # exact ties
+    head[5 + rng.integers(0, 5, n_other), hot[n_one:]] = rng.uniform(0.5, 1.0, n_other)
+    want = oracle.postprocess(head, 640, 640)
+    got, n_kept, n_cand = eng16.postprocess(head, 640, 640)
+    assert n_cand == n_one + n_other and n_kept == len(want) and det_fields_equal(got, want)
+
+
 def test_postprocess_ties_threshold_and_empty(eng16, oracle):
     head = np.zeros((4 + 4, 8), dtype=np.float32)
     head[0] = [50, 60, 300, 300, 300, 100, 100, 100]; head[1] = 100
