@@ -34,11 +34,15 @@ template <> __device__ __forceinline__ float silu<float>(float v) { return v / (
 // rounded to bf16 (8 bits) anyway.  The epilogue was the largest VALU consumer of the LDS kernel.
 template <> __device__ __forceinline__ float silu<bf16_t>(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.442695041f)); }
 
-__device__ __forceinline__ void store4(bf16_t* p, f32x4 v) {
-    bf16x4 o;
-    o[0] = (bf16_t)v[0]; o[1] = (bf16_t)v[1]; o[2] = (bf16_t)v[2]; o[3] = (bf16_t)v[3];
-    *reinterpret_cast<bf16x4*>(p) = o;
+// fp32 -> bf16 of whole vectors: __builtin_convertvector becomes v_cvt_pk_bf16_f32 with two live operands; element-wise casts became one
+// convert per value plus v_perm packing (same round-to-nearest-even, same bits)
+__device__ __forceinline__ bf16x4 to_bf16x4(f32x4 v) { return __builtin_convertvector(v, bf16x4); }
+__device__ __forceinline__ bf16x8 to_bf16x8(f32x4 a, f32x4 b) {
+    typedef __attribute__((ext_vector_type(8))) float f32x8;
+    const f32x8 ab = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_convertvector(ab, bf16x8);
 }
+__device__ __forceinline__ void store4(bf16_t* p, f32x4 v) { *reinterpret_cast<bf16x4*>(p) = to_bf16x4(v); }
 __device__ __forceinline__ void store4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 __device__ __forceinline__ f32x4 load4(const bf16_t* p) {
     bf16x4 i = *reinterpret_cast<const bf16x4*>(p);
@@ -47,12 +51,7 @@ __device__ __forceinline__ f32x4 load4(const bf16_t* p) {
 }
 __device__ __forceinline__ f32x4 load4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 // 8 consecutive channels (two MFMA tiles of a pair): one 16-byte bf16 store / two 16-byte fp32 stores
-__device__ __forceinline__ void store8(bf16_t* p, f32x4 a, f32x4 b) {
-    bf16x8 o;
-    o[0] = (bf16_t)a[0]; o[1] = (bf16_t)a[1]; o[2] = (bf16_t)a[2]; o[3] = (bf16_t)a[3];
-    o[4] = (bf16_t)b[0]; o[5] = (bf16_t)b[1]; o[6] = (bf16_t)b[2]; o[7] = (bf16_t)b[3];
-    *reinterpret_cast<bf16x8*>(p) = o;
-}
+__device__ __forceinline__ void store8(bf16_t* p, f32x4 a, f32x4 b) { *reinterpret_cast<bf16x8*>(p) = to_bf16x8(a, b); }
 __device__ __forceinline__ void store8(float* p, f32x4 a, f32x4 b) { *reinterpret_cast<f32x4*>(p) = a; *reinterpret_cast<f32x4*>(p + 4) = b; }
 __device__ __forceinline__ void load8(const bf16_t* p, f32x4& a, f32x4& b) {
     const bf16x8 i = *reinterpret_cast<const bf16x8*>(p);

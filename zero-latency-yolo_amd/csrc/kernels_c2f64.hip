@@ -58,9 +58,7 @@ __host__ __device__ inline C64Layout c64_layout(int mode, int th, int tw, int nk
 __device__ __forceinline__ bf16x8 c64_ld(__amdgpu_buffer_rsrc_t r, int voff, int soff) { return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0)); }
 __device__ __forceinline__ void c64_st8(__amdgpu_buffer_rsrc_t r, int voff, f32x4 a, f32x4 b)
 {
-    bf16x8 o;
-    o[0] = (bf16_t)a[0]; o[1] = (bf16_t)a[1]; o[2] = (bf16_t)a[2]; o[3] = (bf16_t)a[3];
-    o[4] = (bf16_t)b[0]; o[5] = (bf16_t)b[1]; o[6] = (bf16_t)b[2]; o[7] = (bf16_t)b[3];
+    const bf16x8 o = to_bf16x8(a, b);
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), r, voff, 0, 0);
 }
 

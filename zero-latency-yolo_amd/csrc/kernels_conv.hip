@@ -115,9 +115,7 @@ __device__ __forceinline__ void epilogue_px_buf(const ConvArgs& a, __amdgpu_buff
                 lo += f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
                 hi += f32x4{(float)r[4], (float)r[5], (float)r[6], (float)r[7]};
             }
-            bf16x8 w;
-            w[0] = (bf16_t)lo[0]; w[1] = (bf16_t)lo[1]; w[2] = (bf16_t)lo[2]; w[3] = (bf16_t)lo[3];
-            w[4] = (bf16_t)hi[0]; w[5] = (bf16_t)hi[1]; w[6] = (bf16_t)hi[2]; w[7] = (bf16_t)hi[3];
+            const bf16x8 w = to_bf16x8(lo, hi);
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, w), rout, ob + ch * 2, 0, 0);
         } else if (!(even0 && (c % 2 == 1) && (tile < paired))) {      // second tile of a pair already written above
             f32x4 x = o[c];
@@ -125,8 +123,7 @@ __device__ __forceinline__ void epilogue_px_buf(const ConvArgs& a, __amdgpu_buff
                 const bf16x4 r = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(rres, rb + ch * 2, 0, 0));
                 x += f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
             }
-            bf16x4 w;
-            w[0] = (bf16_t)x[0]; w[1] = (bf16_t)x[1]; w[2] = (bf16_t)x[2]; w[3] = (bf16_t)x[3];
+            const bf16x4 w = to_bf16x4(x);
             typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, w), rout, ob + ch * 2, 0, 0);
         }
@@ -422,9 +419,7 @@ __global__ __launch_bounds__(256) void conv1x1_stream_kernel(const ConvArgs a, i
                 f32x4 lo = acc[c][t] + biasr[c], hi = acc[c + 1][t] + biasr[c + 1];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { lo[r] = silu<bf16_t>(lo[r]); hi[r] = silu<bf16_t>(hi[r]); }
-                bf16x8 o;
-                o[0] = (bf16_t)lo[0]; o[1] = (bf16_t)lo[1]; o[2] = (bf16_t)lo[2]; o[3] = (bf16_t)lo[3];
-                o[4] = (bf16_t)hi[0]; o[5] = (bf16_t)hi[1]; o[6] = (bf16_t)hi[2]; o[7] = (bf16_t)hi[3];
+                const bf16x8 o = to_bf16x8(lo, hi);
                 // the group offset goes into the VGPR offset, not soffset: with an SGPR soffset hipcc emits no wait state
                 // between a 16-byte buffer store and the next VALU write of its data registers (LLVM's hazard rule
                 // exempts that form), and on gfx950 lanes 12-15 of dword 1 were then stored from the overwritten register
@@ -1054,9 +1049,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ws_kernel(const ConvArgs a, co
                         lo += f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
                         hi += f32x4{(float)r[4], (float)r[5], (float)r[6], (float)r[7]};
                     }
-                    bf16x8 wv;
-                    wv[0] = (bf16_t)lo[0]; wv[1] = (bf16_t)lo[1]; wv[2] = (bf16_t)lo[2]; wv[3] = (bf16_t)lo[3];
-                    wv[4] = (bf16_t)hi[0]; wv[5] = (bf16_t)hi[1]; wv[6] = (bf16_t)hi[2]; wv[7] = (bf16_t)hi[3];
+                    const bf16x8 wv = to_bf16x8(lo, hi);
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, wv), rout, ob[h2], 0, 0);
                 } else {
                     f32x4 x = o[0];
@@ -1064,8 +1057,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ws_kernel(const ConvArgs a, co
                         const bf16x4 r = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(rres, rb[h2], 0, 0));
                         x += f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
                     }
-                    bf16x4 wv;
-                    wv[0] = (bf16_t)x[0]; wv[1] = (bf16_t)x[1]; wv[2] = (bf16_t)x[2]; wv[3] = (bf16_t)x[3];
+                    const bf16x4 wv = to_bf16x4(x);
                     typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
                     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, wv), rout, ob[h2], 0, 0);
                 }

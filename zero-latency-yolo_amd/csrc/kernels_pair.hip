@@ -377,13 +377,11 @@ __global__ __launch_bounds__(NW * 64) void c2f_kernel(const C2fArgs a)
     const __amdgpu_buffer_rsrc_t rcat = __builtin_amdgcn_make_buffer_rsrc(a.cat, 0, (unsigned)((size_t)a.n * a.H * a.W * a.cat_cs * 2), 0x00020000);
     auto put_global = [&](int elem, const f32x4* o) {
         if (C == 16) {
-            bf16x4 v; v[0] = (bf16_t)o[0][0]; v[1] = (bf16_t)o[0][1]; v[2] = (bf16_t)o[0][2]; v[3] = (bf16_t)o[0][3];
+            const bf16x4 v = to_bf16x4(o[0]);
             typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, v), rcat, (elem + kq * 4) * 2, 0, 0);
         } else {
-            bf16x8 v;
-            v[0] = (bf16_t)o[0][0]; v[1] = (bf16_t)o[0][1]; v[2] = (bf16_t)o[0][2]; v[3] = (bf16_t)o[0][3];
-            v[4] = (bf16_t)o[1][0]; v[5] = (bf16_t)o[1][1]; v[6] = (bf16_t)o[1][2]; v[7] = (bf16_t)o[1][3];
+            const bf16x8 v = to_bf16x8(o[0], o[1]);
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rcat, (elem + kq * 8) * 2, 0, 0);
         }
     };

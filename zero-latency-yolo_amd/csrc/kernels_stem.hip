@@ -433,9 +433,7 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 8 : NW == 12 ? 6 : 4) void stem
                 lo[r] = lo[r] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(lo[r] * -1.442695041f));
                 hi[r] = hi[r] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(hi[r] * -1.442695041f));
             }
-            bf16x8 o;
-            o[0] = (bf16_t)lo[0]; o[1] = (bf16_t)lo[1]; o[2] = (bf16_t)lo[2]; o[3] = (bf16_t)lo[3];
-            o[4] = (bf16_t)hi[0]; o[5] = (bf16_t)hi[1]; o[6] = (bf16_t)hi[2]; o[7] = (bf16_t)hi[3];
+            const bf16x8 o = __builtin_convertvector(__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7), bf16x8);
             *reinterpret_cast<bf16x8*>(static_cast<bf16_t*>(a.out1) + (((size_t)f * a.H1 + gy) * a.W1 + gx) * a.out1_cs + a.out1_co + kq * 8) = o;
         }
     };
