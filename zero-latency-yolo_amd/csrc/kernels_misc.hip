@@ -116,58 +116,53 @@ __device__ __forceinline__ void store_px8(float* p, const Px8& v) {
     *reinterpret_cast<f32x4*>(p) = v.lo; *reinterpret_cast<f32x4*>(p + 4) = v.hi;
 }
 
+// SPPF's three chained 5x5 max pools (stride 1, pad 2) of an 8-channel slice of one frame, in LDS.  pool(pool(x)) is the 9x9 pool and the third
+// the 13x13 one, so each stage is a separable radius-2 pool of the previous stage's result: 4 + 4 neighbour reads per pixel and stage (round 3;
+// the first version read radius-6 rows and columns of the input: 12 + 36).  max is exact in any order: same bits.
 template <typename T>
 __global__ __launch_bounds__(256) void sppf_pool_kernel(T* __restrict__ buf, int cs, int c, int H, int W)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int hw = H * W;
-    Px8* A = reinterpret_cast<Px8*>(lds);       // source tile
-    Px8* R2 = A + hw;                           // row maxima, radius 2 / 4 / 6
-    Px8* R4 = R2 + hw;
-    Px8* R6 = R4 + hw;
+    Px8* A = reinterpret_cast<Px8*>(lds);       // current stage's input
+    Px8* R = A + hw;                            // its row maxima
+    Px8* B = R + hw;                            // its output = next stage's input
     const int f = blockIdx.y, c0 = blockIdx.x * 8;
     T* base = buf + (size_t)f * hw * cs + c0;
     for (int px = threadIdx.x; px < hw; px += 256) A[px] = load_px8(base + (size_t)px * cs);
     __syncthreads();
-    for (int px = threadIdx.x; px < hw; px += 256) {
-        const int y = px / W, x = px - y * W;
-        const Px8* row = A + y * W;
-        Px8 m = row[x];
+    for (int stage = 1; stage <= 3; ++stage) {
+        for (int px = threadIdx.x; px < hw; px += 256) {
+            const int y = px / W, x = px - y * W;
+            const Px8* row = A + y * W;
+            Px8 m = row[x];
 #pragma unroll
-        for (int d = 1; d <= 6; ++d) {
-            if (x - d >= 0) m = px_max(m, row[x - d]);
-            if (x + d < W) m = px_max(m, row[x + d]);
-            if (d == 2) R2[px] = m;
-            if (d == 4) R4[px] = m;
+            for (int d = 1; d <= 2; ++d) {
+                if (x - d >= 0) m = px_max(m, row[x - d]);
+                if (x + d < W) m = px_max(m, row[x + d]);
+            }
+            R[px] = m;
         }
-        R6[px] = m;
-    }
-    __syncthreads();
-    for (int px = threadIdx.x; px < hw; px += 256) {
-        const int y = px / W, x = px - y * W;
-        Px8 m2 = R2[px], m4 = R4[px], m6 = R6[px];
+        __syncthreads();
+        for (int px = threadIdx.x; px < hw; px += 256) {
+            const int y = px / W, x = px - y * W;
+            Px8 m = R[px];
 #pragma unroll
-        for (int d = 1; d <= 6; ++d) {
-            const bool up = y - d >= 0, dn = y + d < H;
-            if (d <= 2) {
-                if (up) m2 = px_max(m2, R2[(y - d) * W + x]);
-                if (dn) m2 = px_max(m2, R2[(y + d) * W + x]);
+            for (int d = 1; d <= 2; ++d) {
+                if (y - d >= 0) m = px_max(m, R[(y - d) * W + x]);
+                if (y + d < H) m = px_max(m, R[(y + d) * W + x]);
             }
-            if (d <= 4) {
-                if (up) m4 = px_max(m4, R4[(y - d) * W + x]);
-                if (dn) m4 = px_max(m4, R4[(y + d) * W + x]);
-            }
-            if (up) m6 = px_max(m6, R6[(y - d) * W + x]);
-            if (dn) m6 = px_max(m6, R6[(y + d) * W + x]);
+            B[px] = m;
+            store_px8(base + (size_t)px * cs + stage * c, m);
         }
-        T* o = base + (size_t)px * cs;
-        store_px8(o + c, m2); store_px8(o + 2 * c, m4); store_px8(o + 3 * c, m6);
+        __syncthreads();
+        Px8* t = A; A = B; B = t;
     }
 }
 
 hipError_t launch_sppf_pool(int dtype, void* buf, int cs, int c, int n, int H, int W, hipStream_t s)
 {
-    const size_t lds = (size_t)H * W * 8 * sizeof(float) * 4;
+    const size_t lds = (size_t)H * W * 8 * sizeof(float) * 3;
     if (lds > 160 * 1024 || (c % 8) != 0) return hipErrorInvalidValue;
     dim3 grid(c / 8, n);
     if (dtype == ZLY_DTYPE_BF16) {
