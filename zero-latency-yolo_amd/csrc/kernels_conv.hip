@@ -1144,6 +1144,189 @@ hipError_t ws_init()
     return hipSuccess;
 }
 
+// ------------------------------------------------------------------------------------------------
+// 1x1 convolution, WEIGHT-STATIONARY PER WAVE (bf16, single source, SiLU, Cin = 32 * NK): the K-heavy pointwise layers (C2f cv1 / cv2 and
+// SPPF with 128 .. 1024 input channels).  In the direct kernel a wave walks K with fragments two k-steps in flight: its launch lasts as
+// long as ONE wave's chain of NK / 2 dependent L2 round trips (13 - 18 us for 1.4 - 3.9 GFLOP at batch 64; 205 - 340 TFLOP/s on the
+// YOLOv8-s layers whatever their size).  Here nothing is dependent: a wave loads the weight fragments of its TPW channel tiles for ALL of
+// K into registers once (TPW x NK x 4 VGPRs), the workgroup's pixel tile (NPX consecutive NHWC pixels, all of K) lands in LDS by LDS-DMA in
+// one go, and each wave streams the 16-pixel column tiles past its weights exactly as conv3x3_ws_kernel does (pairs of column tiles,
+// epilogue of one pair beside the MFMAs of the next, no barrier inside a tile).  Workgroup = 4 waves = NWC channel groups x NWP pixel
+// groups; blockIdx.y = block of NWC x TPW channel tiles; persistent over pixel tiles, two workgroups per CU.
+// ------------------------------------------------------------------------------------------------
+struct Ws1Geom { int npx, total_tiles, pitch, nwc, nwp; };
+
+template <int TPW, int NK>
+__global__ __launch_bounds__(256, 2) void conv1x1_ws_kernel(const ConvArgs a, const Ws1Geom g)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p = lane & 15, kq = lane >> 4;
+    const int wc = wave % g.nwc, wp = wave / g.nwc;               // channel group, pixel group of this wave
+    const int tile0 = ((int)blockIdx.y * g.nwc + wc) * TPW;       // this wave's first 16-channel tile
+    const bf16_t* __restrict__ in = static_cast<const bf16_t*>(a.in) + a.in_co;
+
+    bf16x8 w[TPW][NK];
+    {
+        const bf16_t* __restrict__ wb = static_cast<const bf16_t*>(a.wgt) + lane * 8;
+#pragma unroll
+        for (int t = 0; t < TPW; ++t)
+#pragma unroll
+            for (int s = 0; s < NK; ++s) w[t][s] = *reinterpret_cast<const bf16x8*>(wb + ((size_t)(tile0 + t) * a.nk + s) * 512);
+    }
+    f32x4 biasr[TPW];
+    load_bias<TPW>(a, tile0, kq, biasr);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (unsigned)((size_t)a.M * a.out_cs * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(in), 0, (unsigned)(((size_t)a.M * a.in_cs - a.in_co) * 2), 0x00020000);
+    // this lane's first output channel: TPW = 2 -> a pair of tiles (pair-permuted rows): 8 consecutive channels; TPW = 1 -> 4 channels
+    const int ch0 = TPW == 2 ? (tile0 >> 1) * 32 + kq * 8 : tile_channel(tile0, kq, (((a.Cout + 15) >> 4) >> 1) << 1);
+
+    // pixel tile -> LDS by LDS-DMA: wave-instruction k fills the LDS units [64 k, 64 k + 64); lane -> unit -> (pixel, 16-byte piece); the
+    // pitch padding, pixels beyond M and units beyond the tile get an out-of-range offset (zeros)
+    const int upp = a.Cin >> 3, upitch = g.pitch >> 4;
+    const int ndma = (g.npx * upitch + 63) >> 6;
+    const float inv_upitch = 1.0f / (float)upitch;
+    auto dma_patch = [&](int tl) {
+        const int m0 = tl * g.npx;
+        for (int k = wave; k < ndma; k += 4) {
+            const int u = k * 64 + lane;
+            const int q = (int)(((float)u + 0.5f) * inv_upitch), part = u - q * upitch;
+            const bool ok = part < upp && q < g.npx && m0 + q < a.M;
+            const unsigned off = ok ? (unsigned)((m0 + q) * a.in_cs * 2 + part * 16) : 0x80000000u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)(smem + k * 1024), 16, off, 0, 0, 0);
+        }
+    };
+    if ((int)blockIdx.x < g.total_tiles) dma_patch(blockIdx.x);
+    for (int tl = blockIdx.x; tl < g.total_tiles; tl += gridDim.x) {
+        const int m0 = tl * g.npx;
+        const int nct = (min(g.npx, a.M - m0) + 15) >> 4;         // column tiles with at least one pixel
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's pieces of the tile have landed (and its stores of the previous tile are out)
+        __syncthreads();
+        auto pair_setup = [&](int t0, const unsigned char* (&px)[2], int (&ob)[2]) {
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int t = min(t0 + h2 * g.nwp, nct - 1);
+                const int q = t * 16 + p, m = m0 + q;
+                px[h2] = smem + q * g.pitch + kq * 16;
+                const bool ok = (t0 + h2 * g.nwp < nct) && m < a.M;     // a missing second tile: computed on a copy of the last, never stored
+                ob[h2] = ok ? (m * a.out_cs + a.out_co + ch0) * 2 : (int)0x80000000;
+            }
+        };
+        auto pair_mma = [&](const unsigned char* const (&px)[2], f32x4 (&acc)[2][TPW]) {
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                for (int c = 0; c < TPW; ++c) acc[h2][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            constexpr int DEPTH = 3;                            // pixel fragments are read DEPTH k-steps ahead of their MFMAs
+            bf16x8 xf[2][DEPTH + 1];
+#pragma unroll
+            for (int s = 0; s < DEPTH; ++s) { xf[0][s] = *reinterpret_cast<const bf16x8*>(px[0] + s * 64); xf[1][s] = *reinterpret_cast<const bf16x8*>(px[1] + s * 64); }
+#pragma unroll
+            for (int s = 0; s < NK; ++s) {
+                if (s + DEPTH < NK) {
+                    xf[0][(s + DEPTH) % (DEPTH + 1)] = *reinterpret_cast<const bf16x8*>(px[0] + (s + DEPTH) * 64);
+                    xf[1][(s + DEPTH) % (DEPTH + 1)] = *reinterpret_cast<const bf16x8*>(px[1] + (s + DEPTH) * 64);
+                }
+#pragma unroll
+                for (int c = 0; c < TPW; ++c) {
+                    acc[0][c] = mma_step(w[c][s], xf[0][s % (DEPTH + 1)], acc[0][c]);
+                    acc[1][c] = mma_step(w[c][s], xf[1][s % (DEPTH + 1)], acc[1][c]);
+                }
+            }
+        };
+        auto pair_store = [&](const f32x4 (&acc)[2][TPW], const int (&ob)[2]) {
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                f32x4 o[TPW];
+#pragma unroll
+                for (int c = 0; c < TPW; ++c) {
+                    o[c] = acc[h2][c] + biasr[c];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[c][r] = silu<bf16_t>(o[c][r]);
+                }
+                if (TPW == 2) {
+                    const bf16x8 wv = to_bf16x8(o[0], o[TPW - 1]);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, wv), rout, ob[h2], 0, 0);
+                } else {
+                    const bf16x4 wv = to_bf16x4(o[0]);
+                    typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, wv), rout, ob[h2], 0, 0);
+                }
+            }
+        };
+        if (wp < nct) {
+            const unsigned char* pxa[2];
+            int oba[2];
+            f32x4 acca[2][TPW];
+            pair_setup(wp, pxa, oba);
+            pair_mma(pxa, acca);
+            for (int t0 = wp + 2 * g.nwp; t0 < nct; t0 += 2 * g.nwp) {
+                const unsigned char* pxb[2];
+                int obb[2];
+                f32x4 accb[2][TPW];
+                pair_setup(t0, pxb, obb);
+                pair_store(acca, oba);                          // epilogue of the previous pair beside the MFMAs of this one
+                pair_mma(pxb, accb);
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    oba[h2] = obb[h2];
+#pragma unroll
+                    for (int c = 0; c < TPW; ++c) acca[h2][c] = accb[h2][c];
+                }
+            }
+            pair_store(acca, oba);
+        }
+        if (tl + (int)gridDim.x < g.total_tiles) {
+            __syncthreads();                                    // everybody is done reading the tile: the next one may land
+            dma_patch(tl + gridDim.x);
+        }
+    }
+}
+
+typedef void (*conv_ws1_fn)(const ConvArgs, const Ws1Geom);
+static conv_ws1_fn pick_ws1(int tpw, int nk)
+{
+#define ZLY_WS1_CASE(T_, N_) if (tpw == T_ && nk == N_) return conv1x1_ws_kernel<T_, N_>
+    ZLY_WS1_CASE(2, 4); ZLY_WS1_CASE(2, 6); ZLY_WS1_CASE(2, 8); ZLY_WS1_CASE(2, 12); ZLY_WS1_CASE(2, 16);
+    ZLY_WS1_CASE(1, 24); ZLY_WS1_CASE(1, 32);
+#undef ZLY_WS1_CASE
+    return nullptr;
+}
+static int ws1_tpw(int nk) { return nk <= 16 ? 2 : 1; }
+
+// pixel tile: as many pixels as 64 KB of LDS hold (two workgroups per CU), fewer while the launch has less than two workgroups per CU
+static bool ws1_plan(int cin, int cout_pad, int M, Ws1Geom* g, int* ny)
+{
+    const int nk = cin / 32, tpw = ws1_tpw(nk);
+    if (cin % 32 || !pick_ws1(tpw, nk)) return false;
+    const int ntiles = cout_pad / 16;
+    if (cout_pad % 32) return false;
+    const int per = ntiles / tpw;                                 // channel groups (waves' worth) in all
+    g->nwc = per % 4 == 0 ? 4 : per % 2 == 0 ? 2 : 1;
+    g->nwp = 4 / g->nwc;
+    *ny = per / g->nwc;
+    g->pitch = cin * 2 + 32;                                      // conflict-free ds_read_b128 for every Cin % 32 == 0 (tools/lds_pitch.py)
+    int npx = WS_LDS_MAX / g->pitch / 16 * 16;
+    if (npx > 128) npx = 128;
+    const int min_npx = 32 * g->nwp;                              // at least one pair of column tiles per wave
+    while (npx > min_npx && (long)((M + npx - 1) / npx) * *ny < 2L * num_cus()) npx -= 16;
+    if (npx < 16) return false;
+    g->npx = npx;
+    g->total_tiles = (M + npx - 1) / npx;
+    return true;
+}
+
+hipError_t ws1_init()
+{
+    static const int shapes[7][2] = {{2, 4}, {2, 6}, {2, 8}, {2, 12}, {2, 16}, {1, 24}, {1, 32}};
+    for (int i = 0; i < 7; ++i) {
+        hipError_t r = hipFuncSetAttribute((const void*)pick_ws1(shapes[i][0], shapes[i][1]), hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_MAX);
+        if (r != hipSuccess) return r;
+    }
+    return hipSuccess;
+}
+
 static int g_num_cus = 256;
 int num_cus() { return g_num_cus; }
 void set_num_cus(int n) { g_num_cus = n < 1 ? 1 : (n > 256 ? 256 : n); }
@@ -1152,6 +1335,7 @@ void set_num_cus(int n) { g_num_cus = n < 1 ? 1 : (n > 256 ? 256 : n); }
 hipError_t conv_init()
 {
     { hipError_t r = ws_init(); if (r != hipSuccess) return r; }
+    { hipError_t r = ws1_init(); if (r != hipSuccess) return r; }
     static const int pts1[3] = {1, 2, 4}, pts2[2] = {1, 2};
     for (int ct = 2; ct <= 5; ++ct) {
         for (int i = 0; i < 3; ++i) {
@@ -1276,12 +1460,30 @@ static bool pick_ws_config(int stride, int cin, int cout_pad, int n, int Ho, int
     return true;
 }
 
+// weight-stationary 1x1 kernel: single-source pointwise convs with at least four k-steps and enough pixels for the persistent grid
+static bool pick_ws1_config(int cin, int cout_pad, int M, ConvLaunch* cfg)
+{
+    Ws1Geom g{};
+    int ny = 0;
+    if (cin < 128 || !ws1_plan(cin, cout_pad, M, &g, &ny)) return false;
+    const char* mm = getenv("ZLY_WS1_MIN_PX");                      // tuning / tests: force the kernel onto small launches
+    if (M < (mm ? atol(mm) : 4096)) return false;
+    cfg->ws1 = 1; cfg->ct = cout_pad / 16; cfg->pt = g.npx / 16; cfg->ksplit = 1; cfg->fastk = 0; cfg->lds = 0; cfg->stream = 0;
+    return true;
+}
+
 void conv_pick_config(int dtype, int ks, int stride, int cin, int cout_pad, int n, int Ho, int Wo, ConvLaunch* cfg, bool streamable, bool plain)
 {
     const int M = n * Ho * Wo;
-    cfg->ks = ks; cfg->lds = 0; cfg->stream = 0; cfg->wres = 0; cfg->ps = 0;
+    cfg->ks = ks; cfg->lds = 0; cfg->stream = 0; cfg->wres = 0; cfg->ps = 0; cfg->ws1 = 0;
     const bool no_stream = getenv("ZLY_NO_STREAM") != nullptr;             // tuning / tests
+    // ZLY_WS1 (tuning / tests): 0 = never the weight-stationary 1x1 kernel, 1 = for the shapes the streaming kernel does not take, 2 = before it
+    const char* w1 = getenv("ZLY_WS1");
+    const int ws1_mode = w1 ? atoi(w1) : 1;
+    const bool ws1_ok = dtype == ZLY_DTYPE_BF16 && ks == 1 && stride == 1 && streamable && ws1_mode > 0;
+    if (ws1_ok && ws1_mode == 2 && pick_ws1_config(cin, cout_pad, M, cfg)) return;
     if (dtype == ZLY_DTYPE_BF16 && ks == 1 && stride == 1 && streamable && !no_stream && pick_stream_config(cin, cout_pad, M, cfg)) return;
+    if (ws1_ok && pick_ws1_config(cin, cout_pad, M, cfg)) return;
     if (dtype == ZLY_DTYPE_BF16 && ks == 3 && plain && pick_ws_config(stride, cin, cout_pad, n, Ho, Wo, cfg)) return;
     if (dtype == ZLY_DTYPE_BF16 && ks == 3 && pick_lds_config(stride, cin, cout_pad, n, Ho, Wo, cfg)) return;
     conv_pick_direct(dtype, ks, cin, cout_pad, M, cfg);
@@ -1290,7 +1492,7 @@ void conv_pick_config(int dtype, int ks, int stride, int cin, int cout_pad, int 
 void conv_pick_direct(int dtype, int ks, int cin, int cout_pad, int M, ConvLaunch* cfg)
 {
     const int kstep = conv_kstep(dtype);
-    cfg->ks = ks; cfg->stream = 0; cfg->wres = 0; cfg->ps = 0;
+    cfg->ks = ks; cfg->stream = 0; cfg->wres = 0; cfg->ps = 0; cfg->ws1 = 0;
     cfg->fastk = (ks == 3 && cin % kstep == 0) ? 1 : 0;
     cfg->ksplit = 1;
     const int ntiles = cout_pad / 16;
@@ -1327,6 +1529,18 @@ void conv_pick_direct(int dtype, int ks, int cin, int cout_pad, int M, ConvLaunc
 
 hipError_t launch_conv(int dtype, const ConvArgs& a, const ConvLaunch& cfg, hipStream_t s)
 {
+    if (cfg.ws1) {                                                 // weight-stationary 1x1 kernel
+        Ws1Geom g{};
+        int ny = 0;
+        if (dtype != ZLY_DTYPE_BF16 || cfg.ks != 1 || a.stride != 1 || a.pad != 0 || a.in2 || a.res || !a.act || a.out_f32 || a.Cin % 32 || a.nk != a.Cin / 32 ||
+            a.Cout % 32 || a.cout_pad != a.Cout || a.in_cs % 8 || a.in_co % 8 || a.out_cs % 8 || a.out_co % 8 || !ws1_plan(a.Cin, a.cout_pad, a.M, &g, &ny)) return hipErrorInvalidValue;
+        const size_t lds = ((size_t)g.npx * g.pitch + 1023) / 1024 * 1024;
+        int gx = 2 * num_cus() / ny;                               // persistent: two resident workgroups per CU
+        if (gx < 1) gx = 1;
+        if (gx > g.total_tiles) gx = g.total_tiles;
+        hipLaunchKernelGGL(pick_ws1(ws1_tpw(a.nk), a.nk), dim3(gx, ny), dim3(256), lds, s, a, g);
+        return hipGetLastError();
+    }
     if (cfg.ps) {                                                  // weight-stationary 3x3 kernel
         WsGeom g{};
         const int ntiles = a.cout_pad / 16, even = ntiles / 2 * 2;

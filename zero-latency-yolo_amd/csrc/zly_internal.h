@@ -40,7 +40,7 @@ struct ConvArgs {
     const void* in2;  int in2_cs, in2_co, split_c;
 };
 
-struct ConvLaunch { int ks, ct, pt, fastk, ksplit, lds, stream, wres, ps; };
+struct ConvLaunch { int ks, ct, pt, fastk, ksplit, lds, stream, wres, ps, ws1; };
 struct ConvArgsMulti { ConvArgs a[6]; int n; };       // independent convs of one launch (conv_igemm_multi_kernel)
 hipError_t launch_conv_multi(const ConvArgsMulti& m, int ct, hipStream_t s);
 
