@@ -352,7 +352,8 @@ def test_production_kernels_layerwise_vs_oracle(weights_path, oracle, ref_fp32, 
                                        (416, 416, 3, {"ZLY_C2F64": "1"}), (352, 288, 5, {"ZLY_C2F64": "1"}), (224, 416, 4, {"ZLY_C2F32_NW": "8"}),
                                        (352, 288, 5, {"ZLY_C2F32_NW": "16"}), (416, 416, 3, {"ZLY_WS_ROWT": "1"}), (352, 288, 5, {"ZLY_STREAM_CT2": "1"}), (416, 416, 3, {"ZLY_LDS_S2_PT1": "1"}),
                                        (352, 288, 5, {"ZLY_WS1": "2", "ZLY_WS1_MIN_PX": "1"}), (224, 416, 4, {"ZLY_WS1": "2", "ZLY_WS1_MIN_PX": "1"}),
-                                       (416, 416, 3, {"ZLY_WS1": "0"})])
+                                       (416, 416, 3, {"ZLY_WS1": "0"}), (352, 288, 5, {"ZLY_WS1": "2", "ZLY_WS1_MIN_PX": "1", "ZLY_NO_C2F": "1"}),
+                                       (416, 416, 3, {"ZLY_WS1_NO_DUAL": "1"})])
 def test_throughput_kernels_on_ragged_maps(weights_path, oracle, monkeypatch, w, h, n, env):
     """conv3x3_lds_kernel, conv1x1_stream_kernel and bottleneck_pair_kernel forced onto small batches of ragged maps (88x72 ..
     11x9, 104x104 .. 13x13, 56x104 .. 7x13: partial tiles on every edge, 13-row maps, last pixel groups that are not full,
@@ -672,12 +673,16 @@ def test_yolov8s_widths(tmp_path, oracle):
     e.close()
 
 
-def test_yolov8s_640_fp8_weights(tmp_path, oracle):
-    """BASELINE configs[4] as one GPU sees it: YOLOv8-s, 640 x 640, fp8 (e4m3) weights.  The file stores one byte per weight; the
+@pytest.mark.parametrize("env", [{}, {"ZLY_WS1": "2", "ZLY_WS1_MIN_PX": "1"}])
+def test_yolov8s_640_fp8_weights(tmp_path, oracle, monkeypatch, env):
+    """BASELINE configs[4] as one GPU sees it: YOLOv8-s, 640 x 640, fp8 (e4m3) weights (second run: every pointwise conv with >= 128 input
+    channels on the weight-stationary 1x1 kernel -- 4 .. 32 k-steps, one channel tile per wave from 768 inputs up, the Upsample + Concat inputs).  The file stores one byte per weight; the
     loader dequantises to values that are exact in bf16, so the engine must match the oracle ON THE SAME DEQUANTISED WEIGHTS at
     the usual bf16 tolerances: every conv output against the bf16-rounding oracle, the head tensor against the fp32 oracle
     (box <= 1.5 px, score <= 2e-2), detect() == the oracle's post-processing of the engine's own head tensor."""
     import yolov8_ref
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
     spec = zm.build_spec("s")
     p = str(tmp_path / "yolov8s_synth_fp8.zlyw")
     zm.write_zlyw(p, spec, zm.synth_weights(spec, seed=9), fp8=True)

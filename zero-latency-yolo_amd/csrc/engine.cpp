@@ -709,7 +709,8 @@ static const ConvLaunch& conv_launch_of(zly_engine* e, const Op& op, int n)
         ConvLaunch c;
         conv_pick_config(e->dtype, op.ks, op.stride, cin, op.cout_pad, n, ob.H, ob.W, &c,
                          op.in2.buf < 0 && op.res.buf < 0 && op.act && !op.out_f32 && op.cout % 32 == 0,
-                         op.in2.buf < 0 && !op.out_f32);
+                         op.in2.buf < 0 && !op.out_f32,
+                         op.in2.buf >= 0 && op.ks == 1 && op.res.buf < 0 && op.act && !op.out_f32 && op.cout % 32 == 0 && op.cout_pad == op.cout);
         it = mop.launch_cache.emplace(n, c).first;
     }
     return it->second;
@@ -2083,7 +2084,7 @@ int32_t zly_op_kernel_name(zly_engine* e, int32_t i, int32_t n, char* out, size_
         if (op.pair && pair_active(e, op, n)) { k = op.pair == 1 ? "bottleneck_pair_kernel<" + std::to_string(op.pair_c) + ">" : "(fused into the previous launch)"; break; }
         const int cin = op.in.C + (op.in2.buf >= 0 ? op.in2.C : 0);
         const ConvLaunch c = conv_launch_of(e, op, n);
-        if (c.ws1) k = "conv1x1_ws_kernel<NK=" + std::to_string(cin / 32) + "," + std::to_string(c.ct) + " channel tiles," + std::to_string(c.pt * 16) + " px>";
+        if (c.ws1) k = std::string("conv1x1_ws_kernel<") + (op.in2.buf >= 0 ? "dual-source," : "") + "NK=" + std::to_string(cin / 32) + "," + std::to_string(c.ct) + " channel tiles," + std::to_string(c.pt * 16) + " px>";
         else if (c.ps) k = "conv3x3_ws_kernel<TPW=2," + std::to_string(c.ct) + " channel tiles>";
         else if (c.lds) k = "conv3x3_lds_kernel<S=" + std::to_string(op.stride) + ",CT=" + std::to_string(c.ct) + ",PT=" + std::to_string(c.pt) + (c.wres ? ",wres>" : ">");
         else if (c.stream) k = "conv1x1_stream_kernel<CT=" + std::to_string(c.ct) + ",PT=" + std::to_string(c.pt) + ",NK=" + std::to_string((cin + 31) / 32) + ">";

@@ -1156,7 +1156,7 @@ hipError_t ws_init()
 // ------------------------------------------------------------------------------------------------
 struct Ws1Geom { int npx, total_tiles, pitch, nwc, nwp; };
 
-template <int TPW, int NK>
+template <int TPW, int NK, bool DUAL = false>
 __global__ __launch_bounds__(256, 2) void conv1x1_ws_kernel(const ConvArgs a, const Ws1Geom g)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1178,7 +1178,9 @@ __global__ __launch_bounds__(256, 2) void conv1x1_ws_kernel(const ConvArgs a, co
     f32x4 biasr[TPW];
     load_bias<TPW>(a, tile0, kq, biasr);
     const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (unsigned)((size_t)a.M * a.out_cs * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(in), 0, (unsigned)(((size_t)a.M * a.in_cs - a.in_co) * 2), 0x00020000);
+    // DUAL (fused nearest-2x Upsample + Concat, see ConvArgs): `in` is the half-size tensor, `in2` the full-size one
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(in), 0, (unsigned)(((size_t)(DUAL ? a.M >> 2 : a.M) * a.in_cs - a.in_co) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rin2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(DUAL ? a.in2 : a.in), 0, (unsigned)((size_t)a.M * (DUAL ? a.in2_cs : a.in_cs) * 2), 0x00020000);
     // this lane's first output channel: TPW = 2 -> a pair of tiles (pair-permuted rows): 8 consecutive channels; TPW = 1 -> 4 channels
     const int ch0 = TPW == 2 ? (tile0 >> 1) * 32 + kq * 8 : tile_channel(tile0, kq, (((a.Cout + 15) >> 4) >> 1) << 1);
 
@@ -1187,16 +1189,36 @@ __global__ __launch_bounds__(256, 2) void conv1x1_ws_kernel(const ConvArgs a, co
     const int upp = a.Cin >> 3, upitch = g.pitch >> 4;
     const int ndma = (g.npx * upitch + 63) >> 6;
     const float inv_upitch = 1.0f / (float)upitch;
+    const int hw = a.H * a.W, spa = a.split_c >> 3;              // DUAL: pixels of a frame, 16-byte pieces that come from `in`
+    const float inv_hw = 1.0f / (float)hw, invW = 1.0f / (float)a.W;
     auto dma_patch = [&](int tl) {
         const int m0 = tl * g.npx;
         for (int k = wave; k < ndma; k += 4) {
             const int u = k * 64 + lane;
             const int q = (int)(((float)u + 0.5f) * inv_upitch), part = u - q * upitch;
             const bool ok = part < upp && q < g.npx && m0 + q < a.M;
-            const unsigned off = ok ? (unsigned)((m0 + q) * a.in_cs * 2 + part * 16) : 0x80000000u;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)(smem + k * 1024), 16, off, 0, 0, 0);
+            auto* dst = (__attribute__((address_space(3))) void*)(smem + k * 1024);
+            if constexpr (!DUAL) {
+                const unsigned off = ok ? (unsigned)((m0 + q) * a.in_cs * 2 + part * 16) : 0x80000000u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, dst, 16, off, 0, 0, 0);
+            } else {
+                // two DMA instructions under complementary EXEC masks (a masked-off lane writes nothing): the pieces of the up-sampled
+                // tensor (and the zero pieces), then those of the full-size one
+                const int m = min(m0 + q, a.M - 1);
+                const int b = (int)(((float)m + 0.5f) * inv_hw), r = m - b * hw;
+                const int y = (int)(((float)r + 0.5f) * invW), x = r - y * a.W;
+                const int ma = (b * (a.H >> 1) + (y >> 1)) * (a.W >> 1) + (x >> 1);
+                if (!ok || part < spa) {
+                    const unsigned off = ok ? (unsigned)(ma * a.in_cs * 2 + part * 16) : 0x80000000u;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, dst, 16, off, 0, 0, 0);
+                } else {
+                    const unsigned off = (unsigned)((m * a.in2_cs + a.in2_co) * 2 + (part - spa) * 16);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rin2, dst, 16, off, 0, 0, 0);
+                }
+            }
         }
     };
+    (void)rin2; (void)inv_hw; (void)invW; (void)spa;
     if ((int)blockIdx.x < g.total_tiles) dma_patch(blockIdx.x);
     for (int tl = blockIdx.x; tl < g.total_tiles; tl += gridDim.x) {
         const int m0 = tl * g.npx;
@@ -1285,9 +1307,14 @@ __global__ __launch_bounds__(256, 2) void conv1x1_ws_kernel(const ConvArgs a, co
 }
 
 typedef void (*conv_ws1_fn)(const ConvArgs, const Ws1Geom);
-static conv_ws1_fn pick_ws1(int tpw, int nk)
+static conv_ws1_fn pick_ws1(int tpw, int nk, bool dual = false)
 {
 #define ZLY_WS1_CASE(T_, N_) if (tpw == T_ && nk == N_) return conv1x1_ws_kernel<T_, N_>
+    if (dual) {                 // the Upsample + Concat inputs of the neck: 192 / 384 channels (YOLOv8n), 384 (YOLOv8-s)
+        if (tpw == 2 && nk == 6) return conv1x1_ws_kernel<2, 6, true>;
+        if (tpw == 2 && nk == 12) return conv1x1_ws_kernel<2, 12, true>;
+        return nullptr;         // 768 channels (one channel tile per wave, four channel blocks that each gather the input): the direct kernel is faster (58 vs 70 us)
+    }
     ZLY_WS1_CASE(2, 4); ZLY_WS1_CASE(2, 6); ZLY_WS1_CASE(2, 8); ZLY_WS1_CASE(2, 12); ZLY_WS1_CASE(2, 16);
     ZLY_WS1_CASE(1, 24); ZLY_WS1_CASE(1, 32);
 #undef ZLY_WS1_CASE
@@ -1296,10 +1323,10 @@ static conv_ws1_fn pick_ws1(int tpw, int nk)
 static int ws1_tpw(int nk) { return nk <= 16 ? 2 : 1; }
 
 // pixel tile: as many pixels as 64 KB of LDS hold (two workgroups per CU), fewer while the launch has less than two workgroups per CU
-static bool ws1_plan(int cin, int cout_pad, int M, Ws1Geom* g, int* ny)
+static bool ws1_plan(int cin, int cout_pad, int M, Ws1Geom* g, int* ny, bool dual = false)
 {
     const int nk = cin / 32, tpw = ws1_tpw(nk);
-    if (cin % 32 || !pick_ws1(tpw, nk)) return false;
+    if (cin % 32 || !pick_ws1(tpw, nk, dual)) return false;
     const int ntiles = cout_pad / 16;
     if (cout_pad % 32) return false;
     const int per = ntiles / tpw;                                 // channel groups (waves' worth) in all
@@ -1307,21 +1334,29 @@ static bool ws1_plan(int cin, int cout_pad, int M, Ws1Geom* g, int* ny)
     g->nwp = 4 / g->nwc;
     *ny = per / g->nwc;
     g->pitch = cin * 2 + 32;                                      // conflict-free ds_read_b128 for every Cin % 32 == 0 (tools/lds_pitch.py)
-    int npx = WS_LDS_MAX / g->pitch / 16 * 16;
-    if (npx > 128) npx = 128;
-    const int min_npx = 32 * g->nwp;                              // at least one pair of column tiles per wave
-    while (npx > min_npx && (long)((M + npx - 1) / npx) * *ny < 2L * num_cus()) npx -= 16;
-    if (npx < 16) return false;
-    g->npx = npx;
-    g->total_tiles = (M + npx - 1) / npx;
+    // pixels per tile: the least work on the busiest of the 2 x 256 resident workgroups -- rounds of tiles x (pixels of a tile + a fixed
+    // per-tile cost: weights, DMA latency, barriers ~ 128 pixels' worth); at most what 64 KB of LDS hold
+    const char* lk = getenv("ZLY_WS1_LDS_KB");                    // tuning aid
+    int npx_max = (lk ? atoi(lk) : 64) * 1024 / g->pitch / 16 * 16;
+    if (npx_max > 256) npx_max = 256;
+    if (npx_max < 16) return false;
+    long best = -1;
+    for (int npx = 16 * g->nwp; npx <= npx_max; npx += 16) {
+        const long tiles = (long)((M + npx - 1) / npx) * *ny;
+        const long rounds = (tiles + 2L * num_cus() - 1) / (2L * num_cus());
+        const long key = rounds * (npx + 128);
+        if (best < 0 || key < best) { best = key; g->npx = npx; }
+    }
+    if (best < 0) return false;
+    g->total_tiles = (M + g->npx - 1) / g->npx;
     return true;
 }
 
 hipError_t ws1_init()
 {
-    static const int shapes[7][2] = {{2, 4}, {2, 6}, {2, 8}, {2, 12}, {2, 16}, {1, 24}, {1, 32}};
-    for (int i = 0; i < 7; ++i) {
-        hipError_t r = hipFuncSetAttribute((const void*)pick_ws1(shapes[i][0], shapes[i][1]), hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_MAX);
+    static const int shapes[9][3] = {{2, 4, 0}, {2, 6, 0}, {2, 8, 0}, {2, 12, 0}, {2, 16, 0}, {1, 24, 0}, {1, 32, 0}, {2, 6, 1}, {2, 12, 1}};
+    for (int i = 0; i < 9; ++i) {
+        hipError_t r = hipFuncSetAttribute((const void*)pick_ws1(shapes[i][0], shapes[i][1], shapes[i][2] != 0), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         if (r != hipSuccess) return r;
     }
     return hipSuccess;
@@ -1461,18 +1496,18 @@ static bool pick_ws_config(int stride, int cin, int cout_pad, int n, int Ho, int
 }
 
 // weight-stationary 1x1 kernel: single-source pointwise convs with at least four k-steps and enough pixels for the persistent grid
-static bool pick_ws1_config(int cin, int cout_pad, int M, ConvLaunch* cfg)
+static bool pick_ws1_config(int cin, int cout_pad, int M, ConvLaunch* cfg, bool dual = false)
 {
     Ws1Geom g{};
     int ny = 0;
-    if (cin < 128 || !ws1_plan(cin, cout_pad, M, &g, &ny)) return false;
+    if (cin < 128 || !ws1_plan(cin, cout_pad, M, &g, &ny, dual)) return false;
     const char* mm = getenv("ZLY_WS1_MIN_PX");                      // tuning / tests: force the kernel onto small launches
     if (M < (mm ? atol(mm) : 4096)) return false;
     cfg->ws1 = 1; cfg->ct = cout_pad / 16; cfg->pt = g.npx / 16; cfg->ksplit = 1; cfg->fastk = 0; cfg->lds = 0; cfg->stream = 0;
     return true;
 }
 
-void conv_pick_config(int dtype, int ks, int stride, int cin, int cout_pad, int n, int Ho, int Wo, ConvLaunch* cfg, bool streamable, bool plain)
+void conv_pick_config(int dtype, int ks, int stride, int cin, int cout_pad, int n, int Ho, int Wo, ConvLaunch* cfg, bool streamable, bool plain, bool dual)
 {
     const int M = n * Ho * Wo;
     cfg->ks = ks; cfg->lds = 0; cfg->stream = 0; cfg->wres = 0; cfg->ps = 0; cfg->ws1 = 0;
@@ -1481,6 +1516,11 @@ void conv_pick_config(int dtype, int ks, int stride, int cin, int cout_pad, int 
     const char* w1 = getenv("ZLY_WS1");
     const int ws1_mode = w1 ? atoi(w1) : 1;
     const bool ws1_ok = dtype == ZLY_DTYPE_BF16 && ks == 1 && stride == 1 && streamable && ws1_mode > 0;
+    if (dual) {             // Upsample + Concat input, otherwise "streamable": the weight-stationary kernel or the direct one
+        if (dtype == ZLY_DTYPE_BF16 && ks == 1 && stride == 1 && ws1_mode > 0 && !getenv("ZLY_WS1_NO_DUAL") && pick_ws1_config(cin, cout_pad, M, cfg, true)) return;
+        conv_pick_direct(dtype, ks, cin, cout_pad, M, cfg);
+        return;
+    }
     if (ws1_ok && ws1_mode == 2 && pick_ws1_config(cin, cout_pad, M, cfg)) return;
     if (dtype == ZLY_DTYPE_BF16 && ks == 1 && stride == 1 && streamable && !no_stream && pick_stream_config(cin, cout_pad, M, cfg)) return;
     if (ws1_ok && pick_ws1_config(cin, cout_pad, M, cfg)) return;
@@ -1532,13 +1572,15 @@ hipError_t launch_conv(int dtype, const ConvArgs& a, const ConvLaunch& cfg, hipS
     if (cfg.ws1) {                                                 // weight-stationary 1x1 kernel
         Ws1Geom g{};
         int ny = 0;
-        if (dtype != ZLY_DTYPE_BF16 || cfg.ks != 1 || a.stride != 1 || a.pad != 0 || a.in2 || a.res || !a.act || a.out_f32 || a.Cin % 32 || a.nk != a.Cin / 32 ||
-            a.Cout % 32 || a.cout_pad != a.Cout || a.in_cs % 8 || a.in_co % 8 || a.out_cs % 8 || a.out_co % 8 || !ws1_plan(a.Cin, a.cout_pad, a.M, &g, &ny)) return hipErrorInvalidValue;
+        const bool dual = a.in2 != nullptr;
+        if (dtype != ZLY_DTYPE_BF16 || cfg.ks != 1 || a.stride != 1 || a.pad != 0 || a.res || !a.act || a.out_f32 || a.Cin % 32 || a.nk != a.Cin / 32 ||
+            a.Cout % 32 || a.cout_pad != a.Cout || a.in_cs % 8 || a.in_co % 8 || a.out_cs % 8 || a.out_co % 8 || !ws1_plan(a.Cin, a.cout_pad, a.M, &g, &ny, dual)) return hipErrorInvalidValue;
+        if (dual && (a.in2_cs % 8 || a.in2_co % 8 || a.split_c % 8 || a.split_c <= 0 || a.split_c >= a.Cin || (a.H & 1) || (a.W & 1) || a.M % (a.H * a.W))) return hipErrorInvalidValue;
         const size_t lds = ((size_t)g.npx * g.pitch + 1023) / 1024 * 1024;
         int gx = 2 * num_cus() / ny;                               // persistent: two resident workgroups per CU
         if (gx < 1) gx = 1;
         if (gx > g.total_tiles) gx = g.total_tiles;
-        hipLaunchKernelGGL(pick_ws1(ws1_tpw(a.nk), a.nk), dim3(gx, ny), dim3(256), lds, s, a, g);
+        hipLaunchKernelGGL(pick_ws1(ws1_tpw(a.nk), a.nk, dual), dim3(gx, ny), dim3(256), lds, s, a, g);
         return hipGetLastError();
     }
     if (cfg.ps) {                                                  // weight-stationary 3x3 kernel

@@ -53,7 +53,8 @@ void set_num_cus(int n);
 hipError_t launch_conv(int dtype, const ConvArgs& a, const ConvLaunch& cfg, hipStream_t s);
 void       conv_pick_config(int dtype, int ks, int stride, int cin, int cout_pad, int n, int Ho, int Wo, ConvLaunch* cfg,
                             bool streamable = false,    // single source, no residual, SiLU, bf16 output, Cout % 32 == 0
-                            bool plain = false);        // single source, activation dtype output: may take the weight-stationary 3x3 kernel
+                            bool plain = false,         // single source, activation dtype output: may take the weight-stationary 3x3 kernel
+                            bool dual = false);         // 1x1 with the fused Upsample + Concat input, otherwise as `streamable`: may take the weight-stationary 1x1 kernel
 hipError_t conv_init();
 int        conv_kstep(int dtype);
 
