@@ -248,13 +248,33 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a)
 
     f32x4 biasr[CT];
     load_bias<CT>(a, blockIdx.y * CT, kq, biasr);         // in flight during the k-loop
-    F wfA[CT], afA[PT], wfB[CT], afB[PT];
-    if (s_begin < s_end) load_step(s_begin, wfA, afA);
-    for (int s = s_begin; s < s_end; s += 2) {
-        if (s + 1 < s_end) load_step(s + 1, wfB, afB);
-        mma_all(wfA, afA);
-        if (s + 2 < s_end) load_step(s + 2, wfA, afA);
-        if (s + 1 < s_end) mma_all(wfB, afB);
+    if constexpr (KSPLIT > 1) {
+        // split-K (the latency path): a wave's quarter of K is 1 .. 18 k-steps and its launch lasts as long as this chain -- with two steps in
+        // flight that was (steps / 2) dependent L2 round trips (wave lifetime 2.5 us of a 4.8 us launch at batch 1).  A ring of DEPTH register
+        // sets, all requested before the first MFMA: one round trip for up to DEPTH steps.  Same MFMA order into the same accumulators: same bits.
+        constexpr int DEPTH = CT * PT <= 2 ? 9 : 6;
+        F wfr[DEPTH][CT], afr[DEPTH][PT];
+#pragma unroll
+        for (int j = 0; j < DEPTH; ++j)
+            if (s_begin + j < s_end) load_step(s_begin + j, wfr[j], afr[j]);
+        for (int s = s_begin; s < s_end; s += DEPTH) {
+#pragma unroll
+            for (int j = 0; j < DEPTH; ++j) {
+                if (s + j < s_end) {
+                    mma_all(wfr[j], afr[j]);
+                    if (s + j + DEPTH < s_end) load_step(s + j + DEPTH, wfr[j], afr[j]);
+                }
+            }
+        }
+    } else {
+        F wfA[CT], afA[PT], wfB[CT], afB[PT];
+        if (s_begin < s_end) load_step(s_begin, wfA, afA);
+        for (int s = s_begin; s < s_end; s += 2) {
+            if (s + 1 < s_end) load_step(s + 1, wfB, afB);
+            mma_all(wfA, afA);
+            if (s + 2 < s_end) load_step(s + 2, wfA, afA);
+            if (s + 1 < s_end) mma_all(wfB, afB);
+        }
     }
 
     if constexpr (KSPLIT > 1) {
