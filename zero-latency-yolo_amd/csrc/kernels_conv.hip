@@ -1522,7 +1522,7 @@ static bool pick_ws1_config(int cin, int cout_pad, int M, ConvLaunch* cfg, bool 
     int ny = 0;
     if (cin < 128 || !ws1_plan(cin, cout_pad, M, &g, &ny, dual)) return false;
     const char* mm = getenv("ZLY_WS1_MIN_PX");                      // tuning / tests: force the kernel onto small launches
-    if (M < (mm ? atol(mm) : 4096)) return false;
+    if (M < (mm ? atol(mm) : 2048)) return false;
     cfg->ws1 = 1; cfg->ct = cout_pad / 16; cfg->pt = g.npx / 16; cfg->ksplit = 1; cfg->fastk = 0; cfg->lds = 0; cfg->stream = 0;
     return true;
 }
