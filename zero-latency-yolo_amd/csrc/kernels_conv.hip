@@ -252,7 +252,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a)
         // split-K (the latency path): a wave's quarter of K is 1 .. 18 k-steps and its launch lasts as long as this chain -- with two steps in
         // flight that was (steps / 2) dependent L2 round trips (wave lifetime 2.5 us of a 4.8 us launch at batch 1).  A ring of DEPTH register
         // sets, all requested before the first MFMA: one round trip for up to DEPTH steps.  Same MFMA order into the same accumulators: same bits.
-        constexpr int DEPTH = CT * PT <= 2 ? 9 : 6;
+        constexpr int DEPTH = CT * PT <= 2 ? 9 : CT * PT == 3 ? 6 : 2;    // 4 / 5 channel tiles (batch-64 launches of the 13 x 13 stage): two sets, as before -- 162 VGPRs cost model.22.cv2.2.1 2 us
         F wfr[DEPTH][CT], afr[DEPTH][PT];
 #pragma unroll
         for (int j = 0; j < DEPTH; ++j)
