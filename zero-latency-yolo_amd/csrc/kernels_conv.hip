@@ -20,6 +20,7 @@
 #include "zly_internal.h"
 #include "conv_device.h"
 #include <type_traits>
+#include <algorithm>
 
 namespace zly {
 
@@ -1541,7 +1542,8 @@ void conv_pick_config(int dtype, int ks, int stride, int cin, int cout_pad, int 
         conv_pick_direct(dtype, ks, cin, cout_pad, M, cfg);
         return;
     }
-    if (ws1_ok && ws1_mode == 2 && pick_ws1_config(cin, cout_pad, M, cfg)) return;
+    // before the streaming kernel: on request, and on the largest maps (YOLOv8-s 640 x 640 P3, 205k pixels: 31 -> 27 and 35 -> 31 us)
+    if (ws1_ok && (ws1_mode == 2 || M >= 131072) && pick_ws1_config(cin, cout_pad, M, cfg)) return;
     if (dtype == ZLY_DTYPE_BF16 && ks == 1 && stride == 1 && streamable && !no_stream && pick_stream_config(cin, cout_pad, M, cfg)) return;
     if (ws1_ok && pick_ws1_config(cin, cout_pad, M, cfg)) return;
     if (dtype == ZLY_DTYPE_BF16 && ks == 3 && plain && pick_ws_config(stride, cin, cout_pad, n, Ho, Wo, cfg)) return;
@@ -1596,6 +1598,15 @@ hipError_t launch_conv(int dtype, const ConvArgs& a, const ConvLaunch& cfg, hipS
         if (dtype != ZLY_DTYPE_BF16 || cfg.ks != 1 || a.stride != 1 || a.pad != 0 || a.res || !a.act || a.out_f32 || a.Cin % 32 || a.nk != a.Cin / 32 ||
             a.Cout % 32 || a.cout_pad != a.Cout || a.in_cs % 8 || a.in_co % 8 || a.out_cs % 8 || a.out_co % 8 || !ws1_plan(a.Cin, a.cout_pad, a.M, &g, &ny, dual)) return hipErrorInvalidValue;
         if (dual && (a.in2_cs % 8 || a.in2_co % 8 || a.split_c % 8 || a.split_c <= 0 || a.split_c >= a.Cin || (a.H & 1) || (a.W & 1) || a.M % (a.H * a.W))) return hipErrorInvalidValue;
+        // 32-bit byte offsets into the buffer resources: a tensor beyond 2 GiB (batch x map x channels far above any configuration run here)
+        // takes the direct kernel's 64-bit addressing instead
+        const size_t widest = (size_t)a.M * (size_t)std::max(std::max(a.in_cs, a.out_cs), dual ? a.in2_cs : 0) * 2;
+        const char* mb = getenv("ZLY_WS1_MAX_BYTES");                // tests: force the fall-back
+        if (widest >= (mb ? (size_t)atoll(mb) : ((size_t)1 << 31))) {
+            ConvLaunch d{};
+            conv_pick_direct(dtype, 1, a.Cin, a.cout_pad, a.M, &d);
+            return launch_conv(dtype, a, d, s);
+        }
         const size_t lds = ((size_t)g.npx * g.pitch + 1023) / 1024 * 1024;
         int gx = 2 * num_cus() / ny;                               // persistent: two resident workgroups per CU
         if (gx < 1) gx = 1;
