@@ -353,7 +353,8 @@ def test_production_kernels_layerwise_vs_oracle(weights_path, oracle, ref_fp32, 
                                        (352, 288, 5, {"ZLY_C2F32_NW": "16"}), (416, 416, 3, {"ZLY_WS_ROWT": "1"}), (352, 288, 5, {"ZLY_STREAM_CT2": "1"}), (416, 416, 3, {"ZLY_LDS_S2_PT1": "1"}),
                                        (352, 288, 5, {"ZLY_WS1": "2", "ZLY_WS1_MIN_PX": "1"}), (224, 416, 4, {"ZLY_WS1": "2", "ZLY_WS1_MIN_PX": "1"}),
                                        (416, 416, 3, {"ZLY_WS1": "0"}), (352, 288, 5, {"ZLY_WS1": "2", "ZLY_WS1_MIN_PX": "1", "ZLY_NO_C2F": "1"}),
-                                       (416, 416, 3, {"ZLY_WS1_NO_DUAL": "1"}), (352, 288, 5, {"ZLY_WS1": "2", "ZLY_WS1_MIN_PX": "1", "ZLY_WS1_MAX_BYTES": "1"})])
+                                       (416, 416, 3, {"ZLY_WS1_NO_DUAL": "1"}), (352, 288, 5, {"ZLY_WS1": "2", "ZLY_WS1_MIN_PX": "1", "ZLY_WS1_MAX_BYTES": "1"}),
+                                       (352, 288, 5, {"ZLY_NO_WS_S2": "1"}), (224, 416, 4, {"ZLY_NO_WS_S2": "1"})])
 def test_throughput_kernels_on_ragged_maps(weights_path, oracle, monkeypatch, w, h, n, env):
     """conv3x3_lds_kernel, conv1x1_stream_kernel and bottleneck_pair_kernel forced onto small batches of ragged maps (88x72 ..
     11x9, 104x104 .. 13x13, 56x104 .. 7x13: partial tiles on every edge, 13-row maps, last pixel groups that are not full,

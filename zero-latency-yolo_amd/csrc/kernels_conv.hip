@@ -874,7 +874,7 @@ struct WsGeom { int TH, TW, tiles_x, tiles_y, total_tiles, pitch, nchunks, nwc, 
 __device__ unsigned long long* g_ws_diag = nullptr;              // diagnostic build only (tools/ws_bench.hip): per-wave phase cycle sums
 #endif
 
-template <int TPW, int NKS, bool RES, bool ROWT = false>
+template <int TPW, int NKS, bool RES, bool ROWT = false, int S = 1>
 __global__ __launch_bounds__(256, 2) void conv3x3_ws_kernel(const ConvArgs a, const WsGeom g)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -883,7 +883,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ws_kernel(const ConvArgs a, co
     // 16-pixel column tile that wraps into the next row (most do at TW = 13) then hits the same banks as 16 consecutive pixels would:
     // conflict-free fragment reads (with PW = TW + 2 three of four reads took 8 LDS cycles instead of 4, and with 18 reads per 36 MFMAs
     // and 8 waves per CU the LDS, not the matrix pipe, set the pace: profiles/r03_ws_kernel_phase_stamps_v2.txt)
-    const int PW = g.TW + 8, PH = g.TH + 2;
+    // S = 2 (the down-sampling convs): the patch is (2 TH + 1) x (2 TW + 1) input pixels, a lane's fragments are two patch pixels apart (pixel pitch
+    // Cin*2 + 16 B: conflict-free at that stride, tools/lds_pitch.py), and the row pitch keeps PW - TW a multiple of 8 for the same reason as above
+    const int PW = S == 1 ? g.TW + 8 : g.TW + 8 * ((g.TW + 8) / 8), PH = S == 1 ? g.TH + 2 : 2 * g.TH + 1;
+    const int PWV = S == 1 ? g.TW + 2 : 2 * g.TW + 1;               // patch columns that hold input pixels
+    static_assert(S == 1 || !ROWT, "row tiles: stride 1");
     const int nthreads = blockDim.x;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -953,8 +957,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ws_kernel(const ConvArgs a, co
             const int u = k * 64 + lane;
             const int px = (int)(((float)u + 0.5f) * inv_upitch), part = u - px * upitch;
             const int py = (int)(((float)px + 0.5f) * invPW), pxx = px - py * PW;
-            const int gy = y0 - 1 + py, gx = x0 - 1 + pxx;
-            const bool ok = part < upp && pxx < g.TW + 2 && py < PH && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+            const int gy = y0 * S - 1 + py, gx = x0 * S - 1 + pxx;
+            const bool ok = part < upp && pxx < PWV && py < PH && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
             const unsigned off = ok ? (unsigned)((((b * a.H + gy) * a.W + gx) * a.in_cs) * 2 + part * 16) : 0x80000000u;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)(dst + k * 1024), 16, off, 0, 0, 0);
         }
@@ -982,7 +986,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ws_kernel(const ConvArgs a, co
                 const int q = ROWT ? (p < g.TW ? t * g.TW + p : NPB) : t * 16 + p;
                 const int qc = min(q, NPB - 1);
                 const int oy = ROWT ? t : (int)(((float)qc + 0.5f) * invTW), ox = ROWT ? p : qc - oy * g.TW;     // ROWT: lanes beyond the row read patch columns that exist (row pitch TW + 8) and store nothing
-                px[h2] = cur + (oy * PW + ox) * g.pitch + kq * 16;
+                px[h2] = cur + (oy * S * PW + ox * S) * g.pitch + kq * 16;
                 const int gy = y0 + oy, gx = x0 + ox;
                 const bool ok = (t0 + h2 * g.nwp < nct) && q < NPB && gy < a.Ho && gx < a.Wo;       // a missing second tile: computed on a copy of the last, never stored
                 const int m = (b * a.Ho + gy) * a.Wo + gx;
@@ -1123,8 +1127,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ws_kernel(const ConvArgs a, co
 }
 
 typedef void (*conv_ws_fn)(const ConvArgs, const WsGeom);
-static conv_ws_fn pick_ws(int cin, int tpw, bool res = false, bool rowt = false)
+static conv_ws_fn pick_ws(int cin, int tpw, bool res = false, bool rowt = false, int stride = 1)
 {
+    if (stride == 2) {          // the down-sampling convs with 32 / 64 input channels and an even number of output tiles; no residual
+        if (res || rowt || tpw != 2) return nullptr;
+        return cin == 64 ? conv3x3_ws_kernel<2, 18, false, false, 2> : cin == 32 ? conv3x3_ws_kernel<2, 9, false, false, 2> : nullptr;
+    }
     if (cin != 64) return nullptr;
     if (rowt && tpw == 2) return res ? conv3x3_ws_kernel<2, 18, true, true> : conv3x3_ws_kernel<2, 18, false, true>;
     if (res) return tpw == 2 ? conv3x3_ws_kernel<2, 18, true> : conv3x3_ws_kernel<1, 18, true>;
@@ -1134,19 +1142,20 @@ static constexpr int WS_LDS_MAX = 64 * 1024;        // two resident workgroups p
 
 // tile shape: among the shapes whose patch lets two workgroups be resident per CU, the one with the least work on the busiest workgroup --
 // rounds of tiles over the 2 x 256 resident workgroups x (pixels of a tile + a fixed per-tile cost); 768 tiles of 9 x 26 lose to 1024 of 13 x 13
-static bool ws_plan(int H, int W, int cin, int n, WsGeom* g)
+static bool ws_plan(int H, int W, int cin, int n, WsGeom* g, int stride = 1)
 {
-    if (!pick_ws(cin, 2)) return false;
-    const int pitch = cin * 2 + 32;
+    if (!pick_ws(cin, 2, false, false, stride)) return false;
+    const int pitch = cin * 2 + (stride == 2 ? 16 : 32);
     long best = -1;
-    for (int th = 4; th <= 32; ++th)
+    for (int th = (stride == 2 ? 2 : 4); th <= 32; ++th)
         for (int tw = 8; tw <= 32; ++tw) {
-            const long lds = ((long)(th + 2) * (tw + 8) * pitch + 1023) / 1024 * 1024;
+            const long ph = stride == 2 ? 2 * th + 1 : th + 2, pw = stride == 2 ? tw + 8 * ((tw + 8) / 8) : tw + 8;
+            const long lds = (ph * pw * pitch + 1023) / 1024 * 1024;
             if (lds > WS_LDS_MAX) continue;
             const int tx = (W + tw - 1) / tw, ty = (H + th - 1) / th;
             const long tiles = (long)tx * ty * n;
             const long rounds = (tiles + 2 * num_cus() - 1) / (2 * num_cus());
-            const long key = rounds * ((th * tw + 15) / 16 * 16 + 64) * 4096 + (th + 2) * (tw + 8);
+            const long key = rounds * ((th * tw + 15) / 16 * 16 + 64) * 4096 + ph * pw;
             if (best < 0 || key < best) { best = key; g->TH = th; g->TW = tw; g->tiles_x = tx; g->tiles_y = ty; }
         }
     if (best < 0) return false;
@@ -1162,6 +1171,10 @@ hipError_t ws_init()
                 hipError_t r = hipFuncSetAttribute((const void*)pick_ws(64, tpw, res != 0, rowt != 0), hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_MAX);
                 if (r != hipSuccess) return r;
             }
+    for (int cin = 32; cin <= 64; cin += 32) {
+        hipError_t r = hipFuncSetAttribute((const void*)pick_ws(cin, 2, false, false, 2), hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_MAX);
+        if (r != hipSuccess) return r;
+    }
     return hipSuccess;
 }
 
@@ -1504,9 +1517,11 @@ static bool pick_ws_config(int stride, int cin, int cout_pad, int n, int Ho, int
 {
     static const bool off = getenv("ZLY_NO_WS") != nullptr;        // tuning / tests
     const int even = cout_pad / 16 / 2 * 2;                         // tiles of the TPW = 2 launch; an odd last tile goes to a TPW = 1 launch
-    if (off || stride != 1 || cout_pad % 16 || (even != 2 && even != 4 && even != 8)) return false;
+    if (off || cout_pad % 16 || (even != 2 && even != 4 && even != 8)) return false;
+    if (stride == 2 && (cout_pad / 16 != even || getenv("ZLY_NO_WS_S2"))) return false;      // tuning / tests
+    if (stride != 1 && stride != 2) return false;
     WsGeom g{};
-    if (!ws_plan(Ho, Wo, cin, n, &g)) return false;
+    if (!ws_plan(Ho, Wo, cin, n, &g, stride)) return false;
     // enough pixels to give each of the 512 resident workgroups a ~13 x 13 tile (the tile planner would happily cut a small launch into
     // tiny tiles): below that the launch belongs to the latency-path kernels
     const double util = (double)Ho * Wo / ((double)g.tiles_x * g.tiles_y * g.TH * g.TW);
@@ -1617,11 +1632,13 @@ hipError_t launch_conv(int dtype, const ConvArgs& a, const ConvLaunch& cfg, hipS
     if (cfg.ps) {                                                  // weight-stationary 3x3 kernel
         WsGeom g{};
         const int ntiles = a.cout_pad / 16, even = ntiles / 2 * 2;
-        if (dtype != ZLY_DTYPE_BF16 || !pick_ws(a.Cin, 2) || a.stride != 1 || a.pad != 1 || a.in2 || a.out_f32 || a.nk != 9 * a.Cin / 32 ||
-            a.in_cs % 8 || a.in_co % 8 || (even != 2 && even != 4 && even != 8) || !ws_plan(a.Ho, a.Wo, a.Cin, a.M / (a.Ho * a.Wo), &g)) return hipErrorInvalidValue;
+        if (dtype != ZLY_DTYPE_BF16 || !pick_ws(a.Cin, 2, false, false, a.stride) || a.pad != 1 || a.in2 || a.out_f32 || a.nk != 9 * a.Cin / 32 ||
+            a.in_cs % 8 || a.in_co % 8 || (even != 2 && even != 4 && even != 8) || !ws_plan(a.Ho, a.Wo, a.Cin, a.M / (a.Ho * a.Wo), &g, a.stride)) return hipErrorInvalidValue;
+        if (a.stride == 2 && (a.res || ntiles != even)) return hipErrorInvalidValue;
         const int n = a.M / (a.Ho * a.Wo);
         g.total_tiles = g.tiles_x * g.tiles_y * n;
-        const size_t lds = ((size_t)(g.TH + 2) * (g.TW + 8) * g.pitch + 1023) / 1024 * 1024;
+        const size_t lds = a.stride == 2 ? ((size_t)(2 * g.TH + 1) * (g.TW + 8 * ((g.TW + 8) / 8)) * g.pitch + 1023) / 1024 * 1024
+                                         : ((size_t)(g.TH + 2) * (g.TW + 8) * g.pitch + 1023) / 1024 * 1024;
         const int gx = g.total_tiles < 2 * num_cus() ? g.total_tiles : 2 * num_cus();      // persistent: two resident workgroups per CU
         // the even tiles: 4 waves = (even / 2) channel groups x pixel groups
         ConvArgs m = a;
@@ -1629,6 +1646,10 @@ hipError_t launch_conv(int dtype, const ConvArgs& a, const ConvLaunch& cfg, hipS
         m.Cout = a.Cout < even * 16 ? a.Cout : even * 16;
         g.nwc = even / 2; g.nwp = 4 / g.nwc;
         static const bool rowt_env = getenv("ZLY_WS_ROWT") != nullptr;            // experiment: one MFMA tile per output row, kx taps by DPP shifts
+        if (a.stride == 2) {
+            hipLaunchKernelGGL(pick_ws(a.Cin, 2, false, false, 2), dim3(gx), dim3(256), lds, s, m, g);
+            return hipGetLastError();
+        }
         hipLaunchKernelGGL(pick_ws(a.Cin, 2, a.res != nullptr, rowt_env && g.TW + 2 <= 16), dim3(gx), dim3(256), lds, s, m, g);
         if (ntiles > even && a.Cout > even * 16) {
             // the odd last tile (pair-permuted rows cover the even tiles only, so it is a plain 16-channel conv of its own): 1 x 4 waves
