@@ -851,8 +851,8 @@ static size_t lds_bytes(int stride, int pt, int ct, int wchunks = 1) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// 3x3 convolution, WEIGHT-STATIONARY PER WAVE (bf16, stride 1, pad 1, Cin = 32 * NKS / 9): the kernel of the FLOP-dense layers -- the
-// Detect branches at P3 / P4 and the 64-channel bottlenecks at 26 x 26.
+// 3x3 convolution, WEIGHT-STATIONARY PER WAVE (bf16, stride S = 1 or 2, pad 1, Cin = 32 * NKS / 9): the kernel of the FLOP-dense layers -- the
+// Detect branches at P3 / P4, the 64-channel bottlenecks at 26 x 26 and (S = 2) the down-sampling convs with 64 input channels.
 //
 // What the stamped builds showed (profiles/r03_lds_kernel_phase_stamps.txt, r03_ps_kernel_phase_stamps.txt): conv3x3_lds_kernel and a
 // first pixel-stationary variant with a weight ring in LDS both ran the P3 stem at ~560 TFLOP/s although their inner loop alone does
