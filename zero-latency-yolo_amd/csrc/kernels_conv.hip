@@ -1370,8 +1370,7 @@ static bool ws1_plan(int cin, int cout_pad, int M, Ws1Geom* g, int* ny, bool dua
     g->pitch = cin * 2 + 32;                                      // conflict-free ds_read_b128 for every Cin % 32 == 0 (tools/lds_pitch.py)
     // pixels per tile: the least work on the busiest of the 2 x 256 resident workgroups -- rounds of tiles x (pixels of a tile + a fixed
     // per-tile cost: weights, DMA latency, barriers ~ 128 pixels' worth); at most what 64 KB of LDS hold
-    const char* lk = getenv("ZLY_WS1_LDS_KB");                    // tuning aid
-    int npx_max = (lk ? atoi(lk) : 64) * 1024 / g->pitch / 16 * 16;
+    int npx_max = WS_LDS_MAX / g->pitch / 16 * 16;                 // (smaller caps, for more co-resident workgroups of other chains, measured: 32 / 48 KB no gain, 16 - 24 KB -1.5 %)
     if (npx_max > 256) npx_max = 256;
     if (npx_max < 16) return false;
     long best = -1;
@@ -1539,7 +1538,7 @@ static bool pick_ws1_config(int cin, int cout_pad, int M, ConvLaunch* cfg, bool 
     if (cin < 128 || !ws1_plan(cin, cout_pad, M, &g, &ny, dual)) return false;
     const char* mm = getenv("ZLY_WS1_MIN_PX");                      // tuning / tests: force the kernel onto small launches
     if (M < (mm ? atol(mm) : 2048)) return false;
-    cfg->ws1 = 1; cfg->ct = cout_pad / 16; cfg->pt = g.npx / 16; cfg->ksplit = 1; cfg->fastk = 0; cfg->lds = 0; cfg->stream = 0;
+    cfg->ws1 = 1; cfg->ct = cout_pad / 16; cfg->pt = g.npx / 16; cfg->ksplit = 1; cfg->fastk = getenv("ZLY_WS1_MAX_BYTES") ? 1 : 0; cfg->lds = 0; cfg->stream = 0;
     return true;
 }
 
@@ -1616,8 +1615,7 @@ hipError_t launch_conv(int dtype, const ConvArgs& a, const ConvLaunch& cfg, hipS
         // 32-bit byte offsets into the buffer resources: a tensor beyond 2 GiB (batch x map x channels far above any configuration run here)
         // takes the direct kernel's 64-bit addressing instead
         const size_t widest = (size_t)a.M * (size_t)std::max(std::max(a.in_cs, a.out_cs), dual ? a.in2_cs : 0) * 2;
-        const char* mb = getenv("ZLY_WS1_MAX_BYTES");                // tests: force the fall-back
-        if (widest >= (mb ? (size_t)atoll(mb) : ((size_t)1 << 31))) {
+        if (cfg.fastk || widest >= ((size_t)1 << 31)) {             // cfg.fastk: ZLY_WS1_MAX_BYTES was set when the shape was picked (tests: force the fall-back)
             ConvLaunch d{};
             conv_pick_direct(dtype, 1, a.Cin, a.cout_pad, a.M, &d);
             return launch_conv(dtype, a, d, s);
