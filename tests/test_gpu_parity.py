@@ -354,7 +354,7 @@ def test_production_kernels_layerwise_vs_oracle(weights_path, oracle, ref_fp32, 
                                        (352, 288, 5, {"ZLY_WS1": "2", "ZLY_WS1_MIN_PX": "1"}), (224, 416, 4, {"ZLY_WS1": "2", "ZLY_WS1_MIN_PX": "1"}),
                                        (416, 416, 3, {"ZLY_WS1": "0"}), (352, 288, 5, {"ZLY_WS1": "2", "ZLY_WS1_MIN_PX": "1", "ZLY_NO_C2F": "1"}),
                                        (416, 416, 3, {"ZLY_WS1_NO_DUAL": "1"}), (352, 288, 5, {"ZLY_WS1": "2", "ZLY_WS1_MIN_PX": "1", "ZLY_WS1_MAX_BYTES": "1"}),
-                                       (352, 288, 5, {"ZLY_NO_WS_S2": "1"}), (224, 416, 4, {"ZLY_NO_WS_S2": "1"})])
+                                       (352, 288, 5, {"ZLY_NO_WS_S2": "1"}), (224, 416, 4, {"ZLY_NO_WS_S2": "1"}), (352, 288, 5, {"ZLY_NO_WS_S2_C32": "1"})])
 def test_throughput_kernels_on_ragged_maps(weights_path, oracle, monkeypatch, w, h, n, env):
     """conv3x3_lds_kernel, conv1x1_stream_kernel and bottleneck_pair_kernel forced onto small batches of ragged maps (88x72 ..
     11x9, 104x104 .. 13x13, 56x104 .. 7x13: partial tiles on every edge, 13-row maps, last pixel groups that are not full,
@@ -363,7 +363,7 @@ def test_throughput_kernels_on_ragged_maps(weights_path, oracle, monkeypatch, w,
     dumped too); ZLY_C2F32_NW: both wave counts of the 32-channel C2f kernel in every mode; ZLY_WS1=2 + ZLY_WS1_MIN_PX=1: the weight-stationary
     1x1 kernel on every single-source pointwise conv with >= 128 input channels (pixel tiles that end mid-column-tile, 4 / 6 / 8 / 12 / 16
     k-steps, one and two channel blocks), ZLY_WS1=0: none of them; ZLY_WS1_MAX_BYTES=1: its fall-back to the direct kernel for tensors
-    beyond 32-bit byte offsets; ZLY_NO_WS_S2=1: the stride-2 convs with 64 input channels on the LDS-tiled kernel instead of the weight-stationary one
+    beyond 32-bit byte offsets; ZLY_NO_WS_S2=1 (ZLY_NO_WS_S2_C32=1): the stride-2 convs with 32 / 64 (32) input channels on the LDS-tiled kernel instead of the weight-stationary one
     (the default runs cover that one: ragged 44x36 -> 22x18 and 28x52 -> 14x26 maps)."""
     import yolov8_ref
     for k, v in dict(ZLY_LDS_MIN_TILES="1", ZLY_STREAM_MIN_GROUPS="1", ZLY_PAIR_MIN_TILES="1", ZLY_WS_MIN_TILES="1", **env).items():

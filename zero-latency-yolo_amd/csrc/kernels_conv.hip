@@ -1129,9 +1129,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ws_kernel(const ConvArgs a, co
 typedef void (*conv_ws_fn)(const ConvArgs, const WsGeom);
 static conv_ws_fn pick_ws(int cin, int tpw, bool res = false, bool rowt = false, int stride = 1)
 {
-    if (stride == 2) {          // the down-sampling convs with 64 input channels and an even number of output tiles; no residual.  (32 input channels were built
-        if (res || rowt || tpw != 2) return nullptr;        // and dropped: all patch DMA and no MFMA work -- model.3 23.2 -> 21.2 us at 416 x 416, but 68 -> 75 us on YOLOv8-s' 320 -> 160 map)
-        return cin == 64 ? conv3x3_ws_kernel<2, 18, false, false, 2> : nullptr;
+    if (stride == 2) {          // the down-sampling convs with 32 / 64 input channels and an even number of output tiles; no residual
+        if (res || rowt || tpw != 2) return nullptr;
+        return cin == 64 ? conv3x3_ws_kernel<2, 18, false, false, 2> : cin == 32 ? conv3x3_ws_kernel<2, 9, false, false, 2> : nullptr;
     }
     if (cin != 64) return nullptr;
     if (rowt && tpw == 2) return res ? conv3x3_ws_kernel<2, 18, true, true> : conv3x3_ws_kernel<2, 18, false, true>;
@@ -1171,8 +1171,8 @@ hipError_t ws_init()
                 hipError_t r = hipFuncSetAttribute((const void*)pick_ws(64, tpw, res != 0, rowt != 0), hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_MAX);
                 if (r != hipSuccess) return r;
             }
-    {
-        hipError_t r = hipFuncSetAttribute((const void*)pick_ws(64, 2, false, false, 2), hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_MAX);
+    for (int cin = 32; cin <= 64; cin += 32) {
+        hipError_t r = hipFuncSetAttribute((const void*)pick_ws(cin, 2, false, false, 2), hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_MAX);
         if (r != hipSuccess) return r;
     }
     return hipSuccess;
@@ -1518,6 +1518,9 @@ static bool pick_ws_config(int stride, int cin, int cout_pad, int n, int Ho, int
     const int even = cout_pad / 16 / 2 * 2;                         // tiles of the TPW = 2 launch; an odd last tile goes to a TPW = 1 launch
     if (off || cout_pad % 16 || (even != 2 && even != 4 && even != 8)) return false;
     if (stride == 2 && (cout_pad / 16 != even || getenv("ZLY_NO_WS_S2"))) return false;      // tuning / tests
+    // 32 input channels at stride 2 are all patch DMA and no MFMA work: taken on maps up to 200k output pixels only (model.3 at 416 x 416: 23.2 -> 21.2 us;
+    // YOLOv8-s' 320 -> 160 map at batch 32, 819k pixels: 68 -> 75 us)
+    if (stride == 2 && cin == 32 && ((long)n * Ho * Wo >= 200000 || getenv("ZLY_NO_WS_S2_C32"))) return false;
     if (stride != 1 && stride != 2) return false;
     WsGeom g{};
     if (!ws_plan(Ho, Wo, cin, n, &g, stride)) return false;
