@@ -33,6 +33,14 @@ $(OUT)/weights.o: $(CSRC)/weights.cpp $(CSRC)/weights.h include/zly.h | $(OUT)
 $(OUT)/libzly.so: $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
 
+# ---- diagnostic build of the engine (never shipped, never loaded by tests / bench.py / the plugin): the same kernels, engine.cpp with -DZLY_DIAG, which
+#      compiles in the result-changing ZLY_ABLATE_SKIP switch of tools/ablate_launches.sh (ZLY_LIB=.../libzly_diag.so python3 bench.py ...)
+diaglib: $(OUT)/libzly_diag.so
+$(OUT)/engine_diag.o: $(CSRC)/engine.cpp $(CSRC)/zly_internal.h $(CSRC)/weights.h include/zly.h | $(OUT)
+	$(HIPCC) $(HIPFLAGS) -DZLY_DIAG=1 -x hip -c $< -o $@
+$(OUT)/libzly_diag.so: $(filter-out $(OUT)/engine.o,$(OBJS)) $(OUT)/engine_diag.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
+
 # ---- in-process RCCL gather of result slabs (include/zly_gather.h): a library of its own -- it links RCCL, and a process that already carries
 #      PyTorch's bundled RCCL (bench.py, the tests) must never load a second one
 $(OUT)/libzly_gather.so: $(CSRC)/gather.cpp include/zly_gather.h | $(OUT)
@@ -88,4 +96,4 @@ $(OUT)/diag_lds: $(PKG)/tools/diag_lds.hip $(CSRC)/kernels_conv.hip $(CSRC)/zly_
 clean:
 	rm -rf $(OUT) oracle/_build
 
-.PHONY: all host oracle weights diag clean
+.PHONY: all host oracle weights diag diaglib clean

@@ -89,7 +89,7 @@ def host_cores():
 FORCE_GATHER = os.environ.get("ZLY_BENCH_FORCE_GATHER") == "1"
 
 
-def run_steps(engs, frame_sets, batch, steps, slabs, stream_ptr, world, gather_out, size=416, k0=0):
+def run_steps(engs, frame_sets, batch, steps, slabs, stream_ptr, world, gather_out, size=416, k0=0, no_gather=False):
     """enqueue `steps` steps (global step numbers k0 .. k0+steps-1), step k on engine k % len(engs).
     One engine: it enqueues on the caller's stream and runs NMS of step k on its own stream beside the first kernels of step k+1
     (ZLY_FLAG_ASYNC_NMS).  Several engines (ZLY_FLAG_SINGLE_CHAIN): each step is one chain of launches on its engine's own stream and
@@ -103,7 +103,7 @@ def run_steps(engs, frame_sets, batch, steps, slabs, stream_ptr, world, gather_o
     n_eng = len(engs)
     ring = len(slabs)
     works, done = {}, {}
-    gather = world > 1 or FORCE_GATHER
+    gather = (world > 1 or FORCE_GATHER) and not no_gather      # no_gather: the same steps without the collective (the gather's share of a step)
     on_gpu = slabs[0].is_cuda
 
     def gather_step(j, lag):
@@ -134,14 +134,14 @@ def run_steps(engs, frame_sets, batch, steps, slabs, stream_ptr, world, gather_o
         e.join(stream_ptr)                             # every engine's last NMS is ordered into the timed stream
 
 
-def timed_blocks(engs, frame_sets, batch, steps, warmup, blocks, slabs, stream_ptr, world, gather_out, size=416):
+def timed_blocks(engs, frame_sets, batch, steps, warmup, blocks, slabs, stream_ptr, world, gather_out, size=416, no_gather=False):
     """`warmup` untimed steps, then `blocks` consecutive blocks of EXACTLY `steps` steps, each bracketed by barrier +
     torch.cuda.synchronize() on both sides and timed with the maximum over ranks.  Returns the list of block times in seconds.
     Why blocks: the chip ramps its clock for the first ~50 steps after an idle phase (measured: 0.94 -> 0.72 ms/step over the first
     60 batch-64 steps, again after 2 s of idling; tools/first_steps.py) -- a single 20-step window measured right after 5 warm-up steps
     lies inside that ramp.  The median block is the steady state the metric is about; all block times are reported."""
     import torch.distributed as dist
-    run_steps(engs, frame_sets, batch, warmup, slabs, stream_ptr, world, gather_out, size, k0=0)
+    run_steps(engs, frame_sets, batch, warmup, slabs, stream_ptr, world, gather_out, size, k0=0, no_gather=no_gather)
     k0 = warmup
     out = []
     for _ in range(blocks):
@@ -150,7 +150,7 @@ def timed_blocks(engs, frame_sets, batch, steps, warmup, blocks, slabs, stream_p
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        run_steps(engs, frame_sets, batch, steps, slabs, stream_ptr, world, gather_out, size, k0=k0)
+        run_steps(engs, frame_sets, batch, steps, slabs, stream_ptr, world, gather_out, size, k0=k0, no_gather=no_gather)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -227,6 +227,33 @@ def host_to_host(threads, seconds=4.0, max_batch=64, engines=1):
     return out
 
 
+def self_launch(n):
+    """bench.py --gpus N (N > 1) without a launcher: run `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>` as a child
+    and hand its one JSON line (rank 0's) through.  Exits non-zero when the node has fewer than N GPUs or the child fails."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n:
+        raise SystemExit(f"--gpus {n} but this node shows {have} GPU(s): refusing to print a line for a configuration that did not run")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    log("self-launch: " + " ".join(cmd))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        raise SystemExit(f"self-launched {n}-rank run failed (rc {r.returncode})")
+    res = json.loads(lines[-1])
+    if res.get("n_gpus") != n or res.get("rccl_ranks") != n:
+        raise SystemExit(f"self-launched run reports n_gpus={res.get('n_gpus')} rccl_ranks={res.get('rccl_ranks')} under --gpus {n}")
+    res["launcher"] = "self (bench.py started torch.distributed.run as a child process)"
+    return json.dumps(res)
+
+
 def main():
     # The driver reads ONE JSON line from stdout.  Libraries underneath print there too (RCCL writes its
     # version banner to stdout when the communicator is created), so everything but the final line is sent
@@ -267,8 +294,15 @@ def run():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" in os.environ and world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: the line would claim a GPU count it did not run on")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Started bare with --gpus N > 1 (no launcher): this process has not touched the GPU yet (torch.cuda.device_count() does not
+        # initialise it), so it becomes the launcher itself -- N fresh ranks under torch.distributed.run as CHILD processes, rank 0's JSON
+        # line relayed, the child's exit code returned.  It never falls through to a one-GPU run that prints n_gpus = 1 under --gpus N.
+        return self_launch(a.gpus)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -334,6 +368,11 @@ def run():
     result = {
         "metric": "frames_per_sec", "value": round(value, 1), "unit": "frames/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 5),
+        # what was timed: `blocks` consecutive blocks of `steps` steps, every block bracketed by barrier + synchronize; value = the MEDIAN block
+        "blocks": n_blocks, "steps_timed": n_blocks * a.steps, "timed_region_s": round(float(sum(bt)), 5), "median_block_s": round(dt, 6),
+        "mean_ms_per_step_all_blocks": round(float(sum(bt)) / (n_blocks * a.steps) * 1e3, 5),
+        # ranks of the RCCL communicator the slab gather ran on (torch.distributed backend nccl = RCCL); 1 = no communicator, no collective
+        "rccl_ranks": (dist.get_world_size() if dist.is_initialized() else 1),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"YOLOv8-{'nano' if a.scale == 'n' else 'small'} {a.size}x{a.size} batch={B} throughput path (BASELINE configs[2]), bf16{', fp8 e4m3 weight file' if a.fp8 else ''}",
                    "detail": f"per MI355X, frames resident in HBM, preprocess+forward+decode+NMS per step" + (f", steps alternate over {n_eng} engine instances whose chains overlap" if n_eng > 1 else "") +
@@ -482,7 +521,13 @@ def run():
             # step left in the ring buffer, so the comparison covers the header and the written detections
             nk = min(int(want[f, :4].view(np.int32)[0]), cap_d)
             assert np.array_equal(mine[f, :16 + 40 * nk], want[f, :16 + 40 * nk]), f"gathered slab of frame {f} of the last step differs from a single-engine run on the same frames"
-        result["gather"] = {"ranks": world, "bytes_per_rank_per_step": B * sb, "frames_checked": int(hd.shape[0]), "equals_single_engine_run": True}
+        result["gather"] = {"ranks": world, "rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "bytes_per_rank_per_step": B * sb,
+                            "frames_checked": int(hd.shape[0]), "equals_single_engine_run": True}
+        # the gather's share of a step: the same steps once more WITHOUT the collective (3 blocks, same bracket, max over ranks)
+        bt_ng = timed_blocks(engs, sets_b, B, a.steps, 0, 3, slabs_head, sp, world, gb_head, a.size, no_gather=True)
+        ms_ng = float(np.median(bt_ng)) / a.steps * 1e3
+        result["gather"]["ms_per_step_without_gather"] = round(ms_ng, 5)
+        result["gather"]["share_of_step"] = round(max(0.0, 1.0 - ms_ng / ms_per_step), 4)
         dist.barrier()
     if rank == 0 and world == 1 and not a.no_extras and default_cfg and os.environ.get("ZLY_BENCH_NO_H2H") != "1":
         for e_ in engs:                # the native driver creates its own engines: free this process's first

@@ -1,7 +1,7 @@
 // test_plugin_stub.cpp -- the plugin's HOST logic with several engines per process, without a GPU: round-robin over the engine handles,
 // re-ordering of results that finish out of order, error frames that keep the sequence dense, hot reload with requests in flight, and WHERE
 // replaced engines are destroyed.  TEST INFRASTRUCTURE: host/hip_inference_engine.cpp is compiled into this binary together with a
-// link-time stub of the C-ABI entry points it calls (zly_create / zly_destroy / zly_submit / zly_wait / zly_get_stats / zly_weights_fp8 /
+// link-time stub of the C-ABI entry points it calls (zly_create / zly_destroy / zly_submit / zly_poll / zly_wait / zly_get_stats / zly_weights_fp8 /
 // zly_default_config / zly_last_error).  The stub is not a CPU fallback of the product: libzly.so has none, and this file is never linked
 // into it.  A fake engine "detects" one box per frame whose fields encode (engine ordinal, device, first pixel of the frame), and
 // finishes its tickets after a per-engine delay, so that engines complete out of order.
@@ -60,6 +60,13 @@ int32_t zly_submit(zly_engine* e, const uint8_t* bgr, size_t nbytes, int32_t w, 
     e->pending[*ticket] = std::make_pair(bgr[0], ready);
     return ZLY_OK;
 }
+int32_t zly_poll(zly_engine* e, uint64_t ticket)
+{
+    std::lock_guard<std::mutex> lk(e->mu);
+    auto it = e->pending.find(ticket);
+    if (it == e->pending.end()) { g_err = "unknown ticket"; return ZLY_ERR_INVALID_ARGUMENT; }
+    return std::chrono::steady_clock::now() >= it->second.second ? ZLY_OK : ZLY_PENDING;
+}
 int32_t zly_wait(zly_engine* e, uint64_t ticket, zly_det* out, int32_t cap, int32_t* n_out)
 {
     std::pair<uint8_t, std::chrono::steady_clock::time_point> p;
@@ -86,9 +93,72 @@ int32_t zly_weights_fp8(const zly_engine*) { return 0; }
 // ------------------------------------------------------------------------------------------------ the test
 using namespace zero_latency;
 
+// ZLY_SIMULATE=1: the reference's simulation mode as an explicit opt-in (onnx_engine.cpp:1133-1177) -- and ONLY as that: a model that fails to load
+// without the switch is an error from initialize(), never random boxes.
+static int simulate_main(const char* report)
+{
+    std::ofstream rep(report);
+    ServerConfig config;
+    config.model_path = "/nonexistent/model.zlyw";
+    config.inference_engine = "hip";
+    // 1. no switch + a model that does not load: initialize() fails, nothing is created, nothing is simulated
+    unsetenv("ZLY_SIMULATE");
+    { std::lock_guard<std::mutex> lk(g_mu); g_fail_create_after = 0; }
+    {
+        auto engine = InferenceEngineManager::getInstance().createEngine("hip", config);
+        auto r = engine->initialize();
+        rep << "no_switch_init_error=" << (r.hasError() ? static_cast<int>(r.error().code) : 0) << "\nno_switch_status_sim=" << engine->getStatus()["simulation_mode"] << "\n";
+        InferenceRequest q; q.width = 2; q.height = 2; q.data.assign(12, 1);
+        rep << "no_switch_submit=" << static_cast<int>(engine->submitInference(q).error().code) << "\n";
+    }
+    // 2. the switch: no engine is created; every frame gets 0-5 random detections in the reference's ranges, in submission order
+    setenv("ZLY_SIMULATE", "1", 1); setenv("ZLY_SIMULATE_SEED", "7", 1);
+    std::vector<std::vector<float>> runs[2];
+    for (int run = 0; run < 2; ++run) {
+        auto engine = InferenceEngineManager::getInstance().createEngine("hip", config);
+        std::mutex mu;
+        std::vector<uint32_t> order;
+        bool ranges = true;
+        int maxn = 0, total = 0;
+        engine->setCallback([&](uint32_t, const GameState& st) {
+            std::lock_guard<std::mutex> lk(mu);
+            order.push_back(st.frame_id);
+            maxn = std::max(maxn, (int)st.detections.size());
+            std::vector<float> flat;
+            for (size_t i = 0; i < st.detections.size(); ++i) {
+                const Detection& d = st.detections[i];
+                ranges = ranges && d.box.x >= 0.1f && d.box.x <= 0.9f && d.box.y >= 0.1f && d.box.y <= 0.9f && d.box.width >= 0.05f && d.box.width <= 0.2f &&
+                         d.box.height >= 0.075f && d.box.height <= 0.3f && d.confidence >= 0.6f && d.confidence <= 1.0f && d.class_id >= 0 && d.class_id <= 3 &&
+                         d.track_id == (uint32_t)i + 1 && d.timestamp > 1600000000000ull;
+                flat.push_back(d.box.x); flat.push_back(d.confidence); flat.push_back((float)d.class_id);
+                ++total;
+            }
+            runs[run].push_back(flat);
+        });
+        if (engine->initialize().hasError()) return 4;
+        for (int i = 0; i < 300; ++i) {
+            InferenceRequest q; q.client_id = 1; q.frame_id = (uint32_t)i; q.timestamp = 5; q.width = 2; q.height = 2; q.data.assign(i % 7 == 0 ? 5 : 12, 1);   // the reference's mode never looks at the pixels
+            if (engine->submitInference(q).hasError()) return 5;
+        }
+        for (int k = 0; k < 4000; ++k) { { std::lock_guard<std::mutex> lk(mu); if (order.size() >= 300) break; } std::this_thread::sleep_for(std::chrono::milliseconds(1)); }
+        auto st = engine->getStatus();
+        engine->shutdown();
+        std::lock_guard<std::mutex> lk(mu);
+        bool in_order = order.size() == 300;
+        for (size_t i = 0; i < order.size(); ++i) in_order = in_order && order[i] == (uint32_t)i;
+        if (run == 0)
+            rep << "sim_count=" << order.size() << "\nsim_in_order=" << in_order << "\nsim_ranges=" << ranges << "\nsim_max_per_frame=" << maxn << "\nsim_total=" << total
+                << "\nsim_status=" << st["simulation_mode"] << "\nsim_status_count=" << st["inference_count"] << "\nsim_worker_threads=" << st["worker_threads"] << "\n";
+    }
+    rep << "sim_same_seed_same_boxes=" << (runs[0] == runs[1]) << "\n";
+    { std::lock_guard<std::mutex> lk(g_mu); rep << "sim_engines_created=" << g_created << "\n"; }
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
     if (argc < 2) return 2;
+    if (argc > 2 && std::string(argv[2]) == "simulate") return simulate_main(argv[1]);
     std::ofstream rep(argv[1]);
     setenv("ZLY_NUM_DEVICES", "2", 1); setenv("ZLY_ENGINES_PER_GPU", "2", 1); setenv("ZLY_MODEL_WATCH_MS", "0", 1);
     const std::string model = std::string(argv[1]) + ".model";

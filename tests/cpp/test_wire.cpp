@@ -119,9 +119,24 @@ int main(int argc, char** argv)
                 wire::FrameData tmp;
                 auto c0 = wire::parseFrameChunk(one.data(), one.size());
                 a2.add(1, c0.value(), &tmp);
-                bad = one; bad[22 + 12] ^= 1; bad[22 + 17] = 1; bad[22 + 21] = 0x60; bad[22 + 22] = 0xEA; bad[22 + 23] = 0; bad[22 + 24] = 0; refinish(bad);   // other width, index 1, offset 60000
+                bad = one; bad[22 + 4] ^= 1; refinish(bad);                                                            // the same piece under another frame timestamp
                 auto c1 = wire::parseFrameChunk(bad.data(), bad.size());
                 rep << "chunk_contradicts=" << (c1.isOk() ? static_cast<int>(a2.add(1, c1.value(), &tmp).error().code) : -static_cast<int>(c1.error().code)) << "\n";
+                // pieces must tile the frame uniformly -- piece i = bytes [i * P, ...): an overlapping piece (index 1 at offset 30000 behind a
+                // 60000-byte piece 0) and a piece whose count does not match ceil(total / P) are refused by the parser itself, before anything is stored
+                bad = one; bad[22 + 17] = 1; bad[22 + 21] = 0x30; bad[22 + 22] = 0x75; bad[22 + 23] = 0; bad[22 + 24] = 0; refinish(bad);   // index 1, offset 30000
+                rep << "chunk_overlap=" << static_cast<int>(wire::parseFrameChunk(bad.data(), bad.size()).error().code) << "\n";
+                bad = one; bad[22 + 19] = 7; refinish(bad);                                                            // 7 pieces claimed for a frame that needs 9
+                rep << "chunk_bad_count=" << static_cast<int>(wire::parseFrameChunk(bad.data(), bad.size()).error().code) << "\n";
+                // ... and ONE datagram cannot make the server allocate gigabytes: a self-consistent first piece of a 30000 x 30000 frame (2.7 GB, 45000 pieces)
+                // parses, and the assembler refuses it (PACKET_TOO_LARGE) without allocating; nothing stays pending
+                bad = one; bad[22 + 12] = 0x30; bad[22 + 13] = 0x75; bad[22 + 14] = 0x30; bad[22 + 15] = 0x75; bad[22 + 19] = 0xC8; bad[22 + 20] = 0xAF; refinish(bad);
+                auto ch = wire::parseFrameChunk(bad.data(), bad.size());
+                wire::FrameAssembler a4(4);
+                rep << "chunk_huge_parse=" << (ch.isOk() ? 0 : static_cast<int>(ch.error().code)) << "\nchunk_huge_add=" << (ch.isOk() ? static_cast<int>(a4.add(3, ch.value(), &tmp).error().code) : -1)
+                    << "\nchunk_huge_pending=" << a4.pending(3) << "\n";
+                wire::FrameAssembler a5(4, 519168);                       // a limit of exactly one model-sized frame admits it
+                rep << "chunk_limit_exact=" << (a5.add(3, c0.value(), &tmp).isOk() ? 1 : 0) << "\n";
                 // eviction: a third incomplete frame of the same client pushes the oldest out
                 wire::FrameAssembler a3(2);
                 for (uint32_t id = 1; id <= 3; ++id) {

@@ -95,3 +95,57 @@ def test_bench_step_loop_gathers_every_step_in_order(n_eng):
             assert streams == [1234] and joins[0][:-2] == [1] * 10     # one engine: the caller's stream, gather of step k-1 behind NMS(k-1) only
         else:
             assert streams == [0] * n_eng and all(l == 0 for j in joins for l in j)   # several: own streams, join on that engine's last call
+
+
+def test_bench_gpus_n_without_launcher_never_prints_a_one_gpu_line():
+    """`bench.py --gpus 8` started bare (no WORLD_SIZE) used to run on one GPU and print n_gpus = 1.  Now it either becomes
+    the launcher of N ranks itself or exits non-zero; on a box with fewer GPUs than asked for (here: none) it must fail WITHOUT a JSON line."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")], r.stdout
+    assert "--gpus 8" in r.stderr
+    # a launcher whose world size disagrees with --gpus is refused as well (in both directions)
+    env2 = dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], capture_output=True, text=True, env=env2, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr and not r.stdout.strip()
+    env3 = dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"], capture_output=True, text=True, env=env3, timeout=300)
+    assert r.returncode != 0 and not r.stdout.strip()
+
+
+def _worker_nogather(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    import bench
+    registry = {}
+    engs = [FakeEngine(registry, 3, rank) for _ in range(3)]
+    sb = engs[0].slab_bytes
+    slabs = [torch.zeros(4 * sb, dtype=torch.uint8) for _ in range(6)]
+    for t in slabs:
+        registry[t.data_ptr()] = t
+    gather_out = [torch.full((world * 4 * sb,), 7, dtype=torch.uint8) for _ in range(2)]
+    bench.run_steps(engs, [torch.zeros(48, dtype=torch.uint8)], 4, 9, slabs, 1234, world, gather_out, no_gather=True)
+    q.put((rank, all(bool((g == 7).all()) for g in gather_out), sum(len(e.calls) for e in engs)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_step_loop_without_gather_leg():
+    """the `gather.share_of_step` leg: the same steps with the collective left out touch no gather buffer and still run every step"""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_nogather, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, untouched, calls in res:
+        assert untouched and calls == 9, rank

@@ -354,7 +354,8 @@ def test_production_kernels_layerwise_vs_oracle(weights_path, oracle, ref_fp32, 
                                        (352, 288, 5, {"ZLY_WS1": "2", "ZLY_WS1_MIN_PX": "1"}), (224, 416, 4, {"ZLY_WS1": "2", "ZLY_WS1_MIN_PX": "1"}),
                                        (416, 416, 3, {"ZLY_WS1": "0"}), (352, 288, 5, {"ZLY_WS1": "2", "ZLY_WS1_MIN_PX": "1", "ZLY_NO_C2F": "1"}),
                                        (416, 416, 3, {"ZLY_WS1_NO_DUAL": "1"}), (352, 288, 5, {"ZLY_WS1": "2", "ZLY_WS1_MIN_PX": "1", "ZLY_WS1_MAX_BYTES": "1"}),
-                                       (352, 288, 5, {"ZLY_NO_WS_S2": "1"}), (224, 416, 4, {"ZLY_NO_WS_S2": "1"}), (352, 288, 5, {"ZLY_NO_WS_S2_C32": "1"})])
+                                       (352, 288, 5, {"ZLY_NO_WS_S2": "1"}), (224, 416, 4, {"ZLY_NO_WS_S2": "1"}), (352, 288, 5, {"ZLY_NO_WS_S2_C32": "1"}),
+                                       (352, 288, 5, {"ZLY_WS_MAX_BYTES": "1"}), (416, 416, 3, {"ZLY_STEM1_VAR": "0"}), (352, 288, 5, {"ZLY_STEM1_VAR": "0"})])
 def test_throughput_kernels_on_ragged_maps(weights_path, oracle, monkeypatch, w, h, n, env):
     """conv3x3_lds_kernel, conv1x1_stream_kernel and bottleneck_pair_kernel forced onto small batches of ragged maps (88x72 ..
     11x9, 104x104 .. 13x13, 56x104 .. 7x13: partial tiles on every edge, 13-row maps, last pixel groups that are not full,
@@ -364,7 +365,8 @@ def test_throughput_kernels_on_ragged_maps(weights_path, oracle, monkeypatch, w,
     1x1 kernel on every single-source pointwise conv with >= 128 input channels (pixel tiles that end mid-column-tile, 4 / 6 / 8 / 12 / 16
     k-steps, one and two channel blocks), ZLY_WS1=0: none of them; ZLY_WS1_MAX_BYTES=1: its fall-back to the direct kernel for tensors
     beyond 32-bit byte offsets; ZLY_NO_WS_S2=1 (ZLY_NO_WS_S2_C32=1): the stride-2 convs with 32 / 64 (32) input channels on the LDS-tiled kernel instead of the weight-stationary one
-    (the default runs cover that one: ragged 44x36 -> 22x18 and 28x52 -> 14x26 maps)."""
+    (the default runs cover that one: ragged 44x36 -> 22x18 and 28x52 -> 14x26 maps); ZLY_WS_MAX_BYTES=1: the weight-stationary 3x3 kernel's fall-back for tensors
+    beyond 32-bit byte offsets; ZLY_STEM1_VAR=0: the front kernel's round-3 staging / tap order (the default, conflict-free one runs in every other case)."""
     import yolov8_ref
     for k, v in dict(ZLY_LDS_MIN_TILES="1", ZLY_STREAM_MIN_GROUPS="1", ZLY_PAIR_MIN_TILES="1", ZLY_WS_MIN_TILES="1", **env).items():
         monkeypatch.setenv(k, v)
@@ -373,6 +375,24 @@ def test_throughput_kernels_on_ragged_maps(weights_path, oracle, monkeypatch, w,
     ref = yolov8_ref.load(weights_path, "bf16")
     want = ref.forward(torch.from_numpy(x)).numpy()
     e = zly.Engine(weights_path, model_w=w, model_h=h, max_batch=n, warmup_runs=0, flags=zly.FLAG_DUMP_LOGITS)
+    # the switches must really have selected what the case is about (as process-static variables they were fixed by the first engine
+    # of the pytest process and these cases never switched kernels); the engine reads them per zly_create / per picked shape now
+    kn = " | ".join(e.op_kernels(n))
+    if "ZLY_NO_WS" in env:
+        assert "conv3x3_ws_kernel<TPW" not in kn and "conv3x3_ws_kernel<ROWT" not in kn, kn
+    elif "ZLY_WS_ROWT" in env:
+        assert "conv3x3_ws_kernel<ROWT" in kn, kn
+    elif not env:
+        assert "conv3x3_ws_kernel<TPW" in kn and "conv3x3_ws_kernel<ROWT" not in kn, kn
+    if "ZLY_C2F32_NW" in env:
+        nws = [s_.split("NW=")[1].split(",")[0] for s_ in e.op_kernels(n) if s_.startswith("c2f_kernel<C=32")]
+        assert nws and all(v == env["ZLY_C2F32_NW"] for v in nws), kn
+    if "ZLY_NO_WS_S2" in env:
+        assert "conv3x3_ws_kernel<S=2" not in kn, kn
+    if env.get("ZLY_WS1") == "0":
+        assert "conv1x1_ws_kernel" not in kn, kn
+    if "ZLY_C2F64" in env:
+        assert "c2f_kernel<C=64" in kn, kn
     got = e.forward(x)
     checked = _check_taps(e, ref, range(n), skip_ok=(".m.0.cv1", ".m.1.cv1"))
     assert len(checked) >= 59, checked
@@ -438,8 +458,18 @@ def test_detect_fp32_matches_full_cpu_pipeline(eng32, oracle, ref_fp32):
         want = oracle.postprocess(head, 416, 416)
         dets, n = eng32.detect(f, cap=512)
         scores = head[4:].max(0)
-        near = np.any(np.abs(scores - 0.5) < 1e-3)
-        if not near and n == len(want):
+        near = bool(np.any(np.abs(scores - 0.5) < 1e-3))
+        # ... or a same-class pair of candidates whose IoU is within 1e-3 of the NMS threshold (a suppression decision may flip)
+        cand = np.nonzero(scores >= 0.5 - 1e-3)[0]
+        cls = head[4:, cand].argmax(0)
+        for i in range(len(cand)):
+            for j in range(i + 1, len(cand)):
+                if cls[i] == cls[j] and abs(oracle.iou(list(head[:4, cand[i]]), list(head[:4, cand[j]])) - 0.45) < 1e-3:
+                    near = True
+        if not near:
+            # no threshold decision is within rounding distance: the fp32 engine must produce EXACTLY the oracle's detections (the
+            # containment branch below used to be taken whenever the counts differed, so a dropped clear detection would have passed)
+            assert n == len(want), (n, len(want))
             assert np.array_equal(dets["class_id"], want["class_id"])
             for k in ("x", "y", "w", "h"):
                 assert np.abs(dets[k] - want[k]).max() <= FP32_BOX_TOL / 416 * 2

@@ -74,6 +74,23 @@ def test_plugin_multi_engine_host_logic_with_stub_engines(tmp_path):
     assert rep["submit_after_shutdown"] == "3" and rep["created_total"] == rep["destroyed_total"] == "9"
 
 
+def test_plugin_simulation_mode_is_an_explicit_opt_in(tmp_path):
+    """SURVEY 8a / VERDICT r03 a14: generateRandomDetections (reference onnx_engine.cpp:1133-1177) exists behind ZLY_SIMULATE=1 only.  Without the
+    switch a model that does not load is MODEL_LOAD_FAILED from initialize() (the reference silently simulates, :70-75); with it no engine is created
+    and every frame -- whatever its bytes, as in the reference -- yields 0-5 boxes in the reference's ranges, in submission order; a fixed seed repeats."""
+    stub = os.path.join(ROOT, "zero-latency-yolo_amd", "_build", "test_plugin_stub")
+    if not os.path.exists(stub):
+        subprocess.run(["make", "-C", ROOT, "host"], check=True, stdout=subprocess.DEVNULL)
+    rep_path = tmp_path / "report.txt"
+    r = subprocess.run([stub, str(rep_path), "simulate"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    rep = dict(line.split("=", 1) for line in rep_path.read_text().splitlines())
+    assert rep["no_switch_init_error"] == "202" and rep["no_switch_status_sim"] == "false" and rep["no_switch_submit"] == "3"
+    assert rep["sim_count"] == "300" and rep["sim_in_order"] == "1" and rep["sim_ranges"] == "1" and rep["sim_status"] == "true"
+    assert rep["sim_max_per_frame"] == "5" and 500 < int(rep["sim_total"]) < 1000 and rep["sim_status_count"] == "300"
+    assert rep["sim_same_seed_same_boxes"] == "1" and rep["sim_engines_created"] == "0" and rep["sim_worker_threads"] == "0"
+
+
 @pytest.mark.gpu
 def test_host_engine_matches_c_abi_and_oracle(tmp_path, weights_path, oracle):
     import zly

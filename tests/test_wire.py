@@ -97,6 +97,9 @@ def test_chunked_raw_frame_reassembly_matches_oracle(tmp_path):
     assert rep["chunks_serialize"] == "0" and got == pk                                     # the C++ cutter == the oracle, byte for byte
     assert rep["chunk_past_end"] == "103" and rep["chunk_bad_index"] == "103" and rep["chunk_contradicts"] == "103"    # INVALID_PACKET
     assert rep["chunk_evicted"] == "1" and rep["chunk_pending_after"] == "2"
+    # non-uniform tilings are refused by the parser; a datagram that claims a 2.7 GB frame allocates nothing
+    assert rep["chunk_overlap"] == "103" and rep["chunk_bad_count"] == "103"
+    assert rep["chunk_huge_parse"] == "0" and rep["chunk_huge_add"] == "104" and rep["chunk_huge_pending"] == "0" and rep["chunk_limit_exact"] == "1"
 
 
 def test_wire_oracle_matches_committed_vectors():

@@ -175,7 +175,7 @@ struct zly_engine {
     std::atomic<Ingest*> ingest{nullptr};   // created by the first zly_submit (under mu), read lock-free afterwards
 
     // tuning / test switches of the environment, read ONCE at zly_create (they used to be read per launch)
-    struct Switches { bool no_c2f = false, no_det_merge = false, no_tail_split = false, no_lanes = false; std::string ablate; } sw;
+    struct Switches { bool no_c2f = false, no_det_merge = false, no_tail_split = false, no_lanes = false, nms_general = false; int stem1_nw = 0, stem1_var = 1; std::string ablate; } sw;
 
     std::mutex mu;                    // serialises every call that touches engine / device state
     mutable std::mutex stats_mu;      // guards `stats` only, never held across a device call: zly_get_stats cannot wait on a batch
@@ -385,7 +385,18 @@ struct PlanBuilder {
     }
 };
 
-static int build_plan(zly_engine* e, std::string* err)
+// build_plan runs in two halves: the HOST half -- the op list and every weight repack into a host image of the device blob -- needs no
+// device call and runs before zly_create takes the process-wide exclusive gate; the DEVICE half (hipMalloc / hipMemcpy, pointers into the blob) runs
+// under it.  A hot reload builds its new engines beside running ones: their enqueue sections now stall for the allocations only, not for the repack.
+struct PendingLevel { size_t wb, bb, wc, bc; int hb2, hc2, hout; };
+struct PlanState {
+    std::vector<uint8_t> blob;
+    size_t stem_w = 0, stem_b = 0, m1_w = 0, m1_b = 0, stem_w0p = 0;
+    int a0 = -1, a1 = -1;
+    PendingLevel pend[3] = {};
+};
+
+static int build_plan_host(zly_engine* e, PlanState* ps, std::string* err)
 {
     PlanBuilder pb;
     pb.e = e;
@@ -427,7 +438,7 @@ static int build_plan(zly_engine* e, std::string* err)
     e->stem_fused = e->dtype == ZLY_DTYPE_BF16 && (ch[0] == 16 || ch[0] == 32);          // YOLOv8n / YOLOv8-s stems: preprocess + model.0 in one kernel
     if (e->stem_fused) ok = ok && pb.pack_only("model.0", 4, &stem_w, &stem_b, &stem_nk, ch[0] == 32) && stem_nk == 2;
     ok = ok && pb.conv({"model.1"}, View{a0, 0, ch[0]}, View{a1, 0, ch[1]});
-    size_t m1_w = 0, m1_b = 0;
+    size_t m1_w = 0, m1_b = 0, stem_w0p = 0;
     e->stem1 = e->stem_fused && ch[0] == 16 && ch[1] == 32 && !(e->cfg.flags & ZLY_FLAG_NO_FUSION) && getenv("ZLY_NO_STEM1") == nullptr && ok;
     if (e->stem1) {
         // model.1 in the fused kernel's tiling: one 16x16x16 MFMA per tap (k = ci), pair-permuted rows, bias in channel order
@@ -438,6 +449,14 @@ static int build_plan(zly_engine* e, std::string* err)
         repack_conv({r}, ch[0], 16, true, &w, &b, &cout, &cout_pad, &nk, true, 4);
         if (nk != 9 || cout_pad != 32 || r->k != 3 || r->stride != 2) e->stem1 = false;
         else { m1_w = pb.append(w.data(), w.size()); m1_b = pb.append(b.data(), b.size() * sizeof(float)); }
+        // the stem's weights once more in the tap order of the fused kernel's conflict-free fragment reads (kernels_stem.hip: STEM1_TAP_SLOT)
+        if (e->stem1) {
+            const ConvRec* r0 = m.find("model.0");
+            int nk0 = 0;
+            repack_conv({r0}, 4, pb.kstep, true, &w, &b, &cout, &cout_pad, &nk0, false, 0, stem1_tap_slot());
+            if (nk0 != 2 || cout_pad != 16) e->stem1 = false;
+            else stem_w0p = pb.append(w.data(), w.size());
+        }
     }
     ok = ok && pb.c2f("model.2", View{a1, 0, ch[1]}, View{a2, 0, ch[1]}, nb[0], true, H4, W4);
     ok = ok && pb.conv({"model.3"}, View{a2, 0, ch[1]}, View{a3, 0, ch[2]});
@@ -476,8 +495,7 @@ static int build_plan(zly_engine* e, std::string* err)
     Op hd;
     hd.kind = OP_HEAD; hd.name = "detect.tail(1x1 convs+DFL+sigmoid+decode)";
     if (hd.name.size() > 47) hd.name.resize(47);
-    struct PendingLevel { size_t wb, bb, wc, bc; int hb2, hc2, hout; };
-    PendingLevel pend[3];
+    PendingLevel (&pend)[3] = ps->pend;
     int block0 = 0;
     for (int l = 0; l < 3 && ok; ++l) {
         const std::string L = std::to_string(l);
@@ -579,6 +597,21 @@ static int build_plan(zly_engine* e, std::string* err)
         if (!det_ok) e->det_stem[0] = -1;
     }
 
+    ps->blob.swap(pb.blob);
+    ps->stem_w = stem_w; ps->stem_b = stem_b; ps->m1_w = m1_w; ps->m1_b = m1_b; ps->stem_w0p = stem_w0p; ps->a0 = a0; ps->a1 = a1;
+    return ZLY_OK;
+}
+
+static int build_plan_device(zly_engine* e, PlanState* ps, std::string* err)
+{
+    const ModelFile& m = e->model;
+    const int W = e->cfg.model_w, H = e->cfg.model_h;
+    const int* ch = m.ch;
+    const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4;
+    const size_t stem_w = ps->stem_w, stem_b = ps->stem_b, m1_w = ps->m1_w, m1_b = ps->m1_b, stem_w0p = ps->stem_w0p;
+    const int a0 = ps->a0, a1 = ps->a1;
+    const PendingLevel (&pend)[3] = ps->pend;
+    struct { std::vector<uint8_t>& blob; } pb{ps->blob};
     // device allocations
     const int B = e->cfg.max_batch;
     for (Buffer& b : e->bufs) {
@@ -604,6 +637,8 @@ static int build_plan(zly_engine* e, std::string* err)
         stem1_plan(H4, W4, &s1.TH, &s1.TW);
         s1.tiles_x = (W4 + s1.TW - 1) / s1.TW; s1.tiles_y = (H4 + s1.TH - 1) / s1.TH;
         s1.dump = (e->cfg.flags & ZLY_FLAG_DUMP_LOGITS) ? 1 : 0;
+        s1.wgt0p = (const char*)e->d_weights + stem_w0p;
+        s1.nw = e->sw.stem1_nw; s1.var = e->sw.stem1_var;
     }
     for (Op& op : e->ops) {
         if (op.kind != OP_HEAD) continue;
@@ -877,7 +912,7 @@ static hipError_t run_op(zly_engine* e, const Op& op, int n, const uint8_t* d_sr
     }
     case OP_NMS:
         return launch_nms(e->cur_cand, e->cur_count, e->N, n, e->cfg.iou_thr, e->nc, e->d_scratch,
-                          d_slabs_out ? d_slabs_out : e->d_slabs, e->cfg.max_dets, tag0, s);
+                          d_slabs_out ? d_slabs_out : e->d_slabs, e->cfg.max_dets, tag0, s, e->sw.nms_general ? 1 : 0);
     }
     return hipErrorInvalidValue;
 }
@@ -916,7 +951,9 @@ static hipError_t run_ops(zly_engine* e, size_t first, size_t last, int n, const
         if (op.kind == OP_CONV && op.lane == 0 && op.name.rfind("model.22.cv2.2.0", 0) == 0) { join_all(); if (r != hipSuccess) break; }
         // ZLY_ABLATE_SKIP=<op name>[,<op name>...]: the named launches are left out (results are garbage): measures what a launch costs the
         // step when several engines' chains overlap, which its isolated duration does not tell (tools/ablate_launches.sh)
+#ifdef ZLY_DIAG         // diagnostic build only (libzly_diag.so): a shipped engine cannot be told to skip launches
         if (!e->sw.ablate.empty() && e->sw.ablate.find("," + op.name + ",") != std::string::npos) continue;
+#endif
         r = run_op(e, op, n, d_src, d_slabs_out, tag0, st);
     }
     if (r == hipSuccess) join_all();
@@ -1016,7 +1053,10 @@ static int run_path(zly_engine* e, int n, const uint8_t* d_src, void* d_slabs_ou
     if (fused && e->stem1) {
         Stem1Args st = e->stem1a;
         st.st.src = d_src; st.st.desc = e->d_desc;
-        if (e->sw.ablate.find(",stem,") == std::string::npos) HIP_TRY(launch_stem_model1(st, n, s), ZLY_ERR_INFERENCE);      // ZLY_ABLATE_SKIP=stem (diagnostic)
+#ifdef ZLY_DIAG
+        if (e->sw.ablate.find(",stem,") != std::string::npos) { /* ZLY_ABLATE_SKIP=stem (libzly_diag.so only) */ } else
+#endif
+        HIP_TRY(launch_stem_model1(st, n, s), ZLY_ERR_INFERENCE);
         first = 3;
     } else if (fused) {
         StemArgs st = e->stem;
@@ -1607,14 +1647,22 @@ int32_t zly_create(const zly_config* cfg, zly_engine** out)
     e->dtype = cfg->dtype;
     e->esz = cfg->dtype == ZLY_DTYPE_BF16 ? 2 : 4;
     e->sw.no_c2f = getenv("ZLY_NO_C2F") != nullptr;
-    if (const char* v = getenv("ZLY_ABLATE_SKIP")) e->sw.ablate = std::string(",") + v + ",";
+#ifdef ZLY_DIAG
+    if (const char* v = getenv("ZLY_ABLATE_SKIP")) e->sw.ablate = std::string(",") + v + ",";       // result-changing: compiled into libzly_diag.so only (tools/ablate_launches.sh)
+#endif
     e->sw.no_det_merge = getenv("ZLY_NO_DET_MERGE") != nullptr;
     e->sw.no_tail_split = getenv("ZLY_NO_TAIL_SPLIT") != nullptr;
     e->sw.no_lanes = getenv("ZLY_NO_LANES") != nullptr || getenv("ZLY_CU_PART") != nullptr;
+    e->sw.nms_general = getenv("ZLY_NMS_GENERAL") != nullptr;                     // tests / A-B: every frame on NMS's eight-wave path
+    if (const char* v = getenv("ZLY_STEM1_NW")) e->sw.stem1_nw = atoi(v);           // tuning aids: waves per workgroup of the front kernel (12 / 16), ...
+    if (const char* v = getenv("ZLY_STEM1_VAR")) e->sw.stem1_var = atoi(v);         // ... and 0 = round 3's staging / tap order (A/B on one box)
     std::string err;
     int rc = load_zlyw(e->weights_path.c_str(), &e->model, &err);        // host only: file parse
     if (rc != ZLY_OK) { delete e; return fail(rc, err); }
     e->nc = e->model.nc;
+    PlanState plan_state;
+    rc = build_plan_host(e, &plan_state, &err);                          // host only: op list + weight repack, outside the gate
+    if (rc != ZLY_OK) { delete e; return fail(rc, err); }
 
     // Everything that allocates on / uploads to the device runs alone in the process (ExclusiveGate): a hot reload builds new engines beside
     // running ones, and a hipMalloc / hipMemcpy here while one of them had a stream capture open failed both sides.
@@ -1651,8 +1699,9 @@ int32_t zly_create(const zly_config* cfg, zly_engine** out)
                   hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming) == hipSuccess;
         }
         if (!sok) return fail(ZLY_ERR_SYSTEM, "hipStreamCreate failed");
-        int prc = build_plan(e, &err);
+        int prc = build_plan_device(e, &plan_state, &err);
         if (prc != ZLY_OK) return fail(prc, err);
+        plan_state.blob = std::vector<uint8_t>();      // the host image of the weight blob is on the device now
 
         const size_t B = (size_t)cfg->max_batch, N = (size_t)e->N;
         bool ok = true;
@@ -1978,7 +2027,7 @@ int32_t zly_postprocess(zly_engine* e, const float* head, int32_t num_classes, i
     if (r == hipSuccess) r = launch_decode((const float*)d, num_classes, num_boxes, 1, (const FrameDesc*)(d + off_desc), conf_thr,
                                            (Cand*)(d + off_cand), (int*)(d + off_cnt), e->stream);
     if (r == hipSuccess) r = launch_nms((const Cand*)(d + off_cand), (int*)(d + off_cnt), num_boxes, 1, iou_thr, num_classes,
-                                        (Cand*)(d + off_scr), d + off_slab, cap, 0, e->stream);
+                                        (Cand*)(d + off_scr), d + off_slab, cap, 0, e->stream, e->sw.nms_general ? 1 : 0);
     if (r == hipSuccess) r = hipMemcpyAsync(hslab.data(), d + off_slab, slab, hipMemcpyDeviceToHost, e->stream);
     if (r == hipSuccess) r = hipStreamSynchronize(e->stream);
     hipFree(d);
@@ -2078,14 +2127,16 @@ int32_t zly_op_kernel_name(zly_engine* e, int32_t i, int32_t n, char* out, size_
         }
         if (c2f_covered(e, op, n)) { k = "(fused into the C2f kernel at " + op.c2f_leader_name + ")"; break; }
         if (c2f_active(e, op, n)) {
-            k = "c2f_kernel<C=" + std::to_string(op.c2f_c) + (op.c2f_mode == 3 ? ",cv1+bottleneck+cv2>" : op.c2f_mode == 1 ? ",cv1+bottleneck>" : ",bottleneck+cv2>");
+            const C2fPlan* pl = c2f_active(e, op, n);
+            k = "c2f_kernel<C=" + std::to_string(op.c2f_c) + (op.c2f_c == 32 ? ",NW=" + std::to_string(pl->nw) : std::string()) +
+                (op.c2f_mode == 3 ? ",cv1+bottleneck+cv2>" : op.c2f_mode == 1 ? ",cv1+bottleneck>" : ",bottleneck+cv2>");
             break;
         }
         if (op.pair && pair_active(e, op, n)) { k = op.pair == 1 ? "bottleneck_pair_kernel<" + std::to_string(op.pair_c) + ">" : "(fused into the previous launch)"; break; }
         const int cin = op.in.C + (op.in2.buf >= 0 ? op.in2.C : 0);
         const ConvLaunch c = conv_launch_of(e, op, n);
         if (c.ws1) k = std::string("conv1x1_ws_kernel<") + (op.in2.buf >= 0 ? "dual-source," : "") + "NK=" + std::to_string(cin / 32) + "," + std::to_string(c.ct) + " channel tiles," + std::to_string(c.pt * 16) + " px>";
-        else if (c.ps) k = std::string("conv3x3_ws_kernel<") + (op.stride == 2 ? "S=2," : "") + "TPW=2," + std::to_string(c.ct) + " channel tiles>";
+        else if (c.ps) k = std::string("conv3x3_ws_kernel<") + (op.stride == 2 ? "S=2," : "") + (c.rowt ? "ROWT," : "") + "TPW=2," + std::to_string(c.ct) + " channel tiles>";
         else if (c.lds) k = "conv3x3_lds_kernel<S=" + std::to_string(op.stride) + ",CT=" + std::to_string(c.ct) + ",PT=" + std::to_string(c.pt) + (c.wres ? ",wres>" : ">");
         else if (c.stream) k = "conv1x1_stream_kernel<CT=" + std::to_string(c.ct) + ",PT=" + std::to_string(c.pt) + ",NK=" + std::to_string((cin + 31) / 32) + ">";
         else k = std::string("conv_igemm_kernel<") + (op.ks == 1 ? (op.in2.buf >= 0 ? "1x1 dual-source" : "1x1") : (c.fastk ? "3x3" : "3x3 generic-K")) +

@@ -1514,7 +1514,7 @@ static bool pick_stream_config(int cin, int cout_pad, int M, ConvLaunch* cfg)
 // enough tiles to fill the chip
 static bool pick_ws_config(int stride, int cin, int cout_pad, int n, int Ho, int Wo, ConvLaunch* cfg)
 {
-    static const bool off = getenv("ZLY_NO_WS") != nullptr;        // tuning / tests
+    const bool off = getenv("ZLY_NO_WS") != nullptr;               // tuning / tests (read per picked shape = once per engine, op and batch size: Op::launch_cache)
     const int even = cout_pad / 16 / 2 * 2;                         // tiles of the TPW = 2 launch; an odd last tile goes to a TPW = 1 launch
     if (off || cout_pad % 16 || (even != 2 && even != 4 && even != 8)) return false;
     if (stride == 2 && (cout_pad / 16 != even || getenv("ZLY_NO_WS_S2"))) return false;      // tuning / tests
@@ -1530,6 +1530,7 @@ static bool pick_ws_config(int stride, int cin, int cout_pad, int n, int Ho, int
     const char* mt = getenv("ZLY_WS_MIN_TILES");
     if (util < 0.7 || (long)n * Ho * Wo < (mt ? atol(mt) : 64) * 169L) return false;     // 64 x 169 pixels (batch 16 at 26 x 26) up: batch 16 +2.8 %, batch 32 +6 % on one engine; 256 before
     cfg->ps = 1; cfg->ct = cout_pad / 16; cfg->pt = 4; cfg->ksplit = 1; cfg->fastk = 1;
+    cfg->rowt = (stride == 1 && getenv("ZLY_WS_ROWT") != nullptr && g.TW + 2 <= 16) ? 1 : 0;      // experiment: one MFMA tile per output row, kx taps by DPP shifts
     return true;
 }
 
@@ -1548,7 +1549,7 @@ static bool pick_ws1_config(int cin, int cout_pad, int M, ConvLaunch* cfg, bool 
 void conv_pick_config(int dtype, int ks, int stride, int cin, int cout_pad, int n, int Ho, int Wo, ConvLaunch* cfg, bool streamable, bool plain, bool dual)
 {
     const int M = n * Ho * Wo;
-    cfg->ks = ks; cfg->lds = 0; cfg->stream = 0; cfg->wres = 0; cfg->ps = 0; cfg->ws1 = 0;
+    cfg->ks = ks; cfg->lds = 0; cfg->stream = 0; cfg->wres = 0; cfg->ps = 0; cfg->ws1 = 0; cfg->rowt = 0;
     const bool no_stream = getenv("ZLY_NO_STREAM") != nullptr;             // tuning / tests
     // ZLY_WS1 (tuning / tests): 0 = never the weight-stationary 1x1 kernel, 1 = for the shapes the streaming kernel does not take, 2 = before it
     const char* w1 = getenv("ZLY_WS1");
@@ -1571,7 +1572,7 @@ void conv_pick_config(int dtype, int ks, int stride, int cin, int cout_pad, int 
 void conv_pick_direct(int dtype, int ks, int cin, int cout_pad, int M, ConvLaunch* cfg)
 {
     const int kstep = conv_kstep(dtype);
-    cfg->ks = ks; cfg->stream = 0; cfg->wres = 0; cfg->ps = 0; cfg->ws1 = 0;
+    cfg->ks = ks; cfg->stream = 0; cfg->wres = 0; cfg->ps = 0; cfg->ws1 = 0; cfg->rowt = 0;
     cfg->fastk = (ks == 3 && cin % kstep == 0) ? 1 : 0;
     cfg->ksplit = 1;
     const int ntiles = cout_pad / 16;
@@ -1636,6 +1637,18 @@ hipError_t launch_conv(int dtype, const ConvArgs& a, const ConvLaunch& cfg, hipS
         if (dtype != ZLY_DTYPE_BF16 || !pick_ws(a.Cin, 2, false, false, a.stride) || a.pad != 1 || a.in2 || a.out_f32 || a.nk != 9 * a.Cin / 32 ||
             a.in_cs % 8 || a.in_co % 8 || (even != 2 && even != 4 && even != 8) || !ws_plan(a.Ho, a.Wo, a.Cin, a.M / (a.Ho * a.Wo), &g, a.stride)) return hipErrorInvalidValue;
         if (a.stride == 2 && (a.res || ntiles != even)) return hipErrorInvalidValue;
+        // 32-bit byte offsets into the buffer resources (and 0x80000000 as the out-of-range sentinel): a tensor of 2 GiB or more takes the LDS-tiled /
+        // direct kernels' 64-bit addressing instead (YOLOv8-s 640 x 640 crosses it near batch 440).  ZLY_WS_MAX_BYTES forces it (tests).
+        {
+            const size_t widest = std::max(std::max((size_t)a.M / ((size_t)a.Ho * a.Wo) * a.H * a.W * (size_t)a.in_cs, (size_t)a.M * (size_t)a.out_cs), a.res ? (size_t)a.M * (size_t)a.res_cs : (size_t)0) * 2;
+            const char* mb = getenv("ZLY_WS_MAX_BYTES");
+            if (widest >= (mb ? (size_t)atoll(mb) : ((size_t)1 << 31))) {
+                ConvLaunch d{};
+                if (!pick_lds_config(a.stride, a.Cin, a.cout_pad, a.M / (a.Ho * a.Wo), a.Ho, a.Wo, &d)) conv_pick_direct(dtype, 3, a.Cin, a.cout_pad, a.M, &d);
+                d.ks = 3;
+                return launch_conv(dtype, a, d, s);
+            }
+        }
         const int n = a.M / (a.Ho * a.Wo);
         g.total_tiles = g.tiles_x * g.tiles_y * n;
         const size_t lds = a.stride == 2 ? ((size_t)(2 * g.TH + 1) * (g.TW + 8 * ((g.TW + 8) / 8)) * g.pitch + 1023) / 1024 * 1024
@@ -1646,12 +1659,11 @@ hipError_t launch_conv(int dtype, const ConvArgs& a, const ConvLaunch& cfg, hipS
         m.cout_pad = even * 16;
         m.Cout = a.Cout < even * 16 ? a.Cout : even * 16;
         g.nwc = even / 2; g.nwp = 4 / g.nwc;
-        static const bool rowt_env = getenv("ZLY_WS_ROWT") != nullptr;            // experiment: one MFMA tile per output row, kx taps by DPP shifts
         if (a.stride == 2) {
             hipLaunchKernelGGL(pick_ws(a.Cin, 2, false, false, 2), dim3(gx), dim3(256), lds, s, m, g);
             return hipGetLastError();
         }
-        hipLaunchKernelGGL(pick_ws(a.Cin, 2, a.res != nullptr, rowt_env && g.TW + 2 <= 16), dim3(gx), dim3(256), lds, s, m, g);
+        hipLaunchKernelGGL(pick_ws(a.Cin, 2, a.res != nullptr, cfg.rowt != 0 && a.Cin == 64 && g.TW + 2 <= 16), dim3(gx), dim3(256), lds, s, m, g);
         if (ntiles > even && a.Cout > even * 16) {
             // the odd last tile (pair-permuted rows cover the even tiles only, so it is a plain 16-channel conv of its own): 1 x 4 waves
             ConvArgs r = a;

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(HEAD_WAVES * 64) void head_fused_kernel(const HeadA
     for (int j = 0; j < EPL; ++j) zero[j] = (T)0.0f;
 
     // class-branch fragments of the tile, every k-step, requested up front
-    constexpr int KMAX = 8;                                  // k-steps of a branch: bf16 80/128 channels -> 3/4, fp32 -> 5/8
+    constexpr int KMAX = HEAD_KMAX;                          // k-steps of a branch: bf16 80/128 channels -> 3/4, fp32 -> 5/8 (launch_head_fused refuses more)
     F xc[KMAX];
     {
         const T* pc = static_cast<const T*>(L.cls_in) + pix * L.cls_cs;
@@ -279,6 +279,8 @@ hipError_t launch_head_fused(int dtype, const HeadArgs& a0, int n, hipStream_t s
     size_t lds = 0;
     for (int l = 0; l < 3; ++l) { const size_t b = (size_t)(4 * a.lv[l].nkb + ctc * a.lv[l].nkc) * 1024; lds = b > lds ? b : lds; }
     if (lds > 64 * 1024) return hipErrorInvalidValue;
+    for (int l = 0; l < 3; ++l)
+        if (a.lv[l].nkb > HEAD_KMAX || a.lv[l].nkc > HEAD_KMAX) return hipErrorInvalidValue;      // the kernel holds a branch's fragments in HEAD_KMAX k-steps of registers: a wider branch would lose its tail k-steps silently
     const int blocks = a.only_level >= 0 ? (a.lv[a.only_level].hw + HEAD_GROUP - 1) / HEAD_GROUP : a.total_blocks;
     hipLaunchKernelGGL(fn, dim3(blocks, n), dim3(HEAD_WAVES * 64), lds, s, a);
     return hipGetLastError();

@@ -671,9 +671,11 @@ hipError_t pair_init()
 static constexpr int C2F_NW16 = 16, C2F_NW32 = 8, C2F_NLD = 4;
 // waves per workgroup of the 32-channel kernel: 16 (128 VGPRs, biases in LDS: four waves per SIMD hide the fragment-read and epilogue latencies
 // behind each other -- neither the vector nor the matrix pipe was half busy with two) except for the front half, which spills at 128 and keeps 8
+// (read where the plan is made -- c2f_plan, cached per engine and shape -- and carried in C2fPlan::nw: as a process-static it could not be switched by a test)
 static int c2f_nw32(int mode)
 {
-    static const int forced = getenv("ZLY_C2F32_NW") ? atoi(getenv("ZLY_C2F32_NW")) : 0;       // tuning / tests: 8 or 16 for every mode
+    const char* fv = getenv("ZLY_C2F32_NW");                                                   // tuning / tests: 8 or 16 for every mode
+    const int forced = fv ? atoi(fv) : 0;
     if (forced == 8 || forced == 16) return forced;
     return mode == 1 ? C2F_NW32 : 16;          // measured at batch 64: back half 40.7 -> 30.2 us, whole block (model.15) 55.9 -> 44.9 us; the front half spills at 128 VGPRs (30.5 -> 34 us)
 }
@@ -702,7 +704,7 @@ bool c2f_plan(int c, int mode, int nk1, int nk2, int cout2, int n, int H, int W,
     double best = 1e30;
     for (int th = 4; th <= 32; ++th) {
         for (int tw = 8; tw <= 64; ++tw) {
-            static const size_t lds_cap = getenv("ZLY_C2F_LDS_KB") ? (size_t)atoi(getenv("ZLY_C2F_LDS_KB")) * 1024 : (size_t)PAIR_LDS_MAX;    // tuning aid
+            const size_t lds_cap = getenv("ZLY_C2F_LDS_KB") ? (size_t)atoi(getenv("ZLY_C2F_LDS_KB")) * 1024 : (size_t)PAIR_LDS_MAX;    // tuning aid
             if (c2f_lds_bytes(c, mode, nk1, nk2, cout2, th, tw) > lds_cap) continue;
             if (const char* ft = getenv("ZLY_C2F_TILE")) { int fth = 0, ftw = 0; if (sscanf(ft, "%d,%d", &fth, &ftw) == 2 && (fth != th || ftw != tw)) continue; }    // tuning aid: only this shape
             if (!(mode & 1) && (th + 4) * (tw + 4) * (c / 8) > nw * 64 * C2F_NLD) continue;
@@ -724,6 +726,7 @@ bool c2f_plan(int c, int mode, int nk1, int nk2, int cout2, int n, int H, int W,
     if (best >= 1e30) return false;
     plan->grid = plan->total_tiles < ncu ? plan->total_tiles : ncu;
     plan->lds_bytes = (int)c2f_lds_bytes(c, mode, nk1, nk2, cout2, plan->th, plan->tw);
+    plan->nw = nw;
     return true;
 }
 
@@ -761,8 +764,9 @@ hipError_t launch_c2f(int c, int mode, const C2fArgs& a, const C2fPlan& plan, hi
     if (a.cat_cs % 8 || a.pair_in_co % c || a.pair_out_co % c || a.out_cs % 8 || a.out_co % 8) return hipErrorInvalidValue;
     if ((mode & 1) && (a.x_cs % 8 || a.x_co % 8 || (a.x2 && (a.x2_cs % 8 || a.x2_co % 8 || a.split_c % 32 || (a.H & 1) || (a.W & 1))))) return hipErrorInvalidValue;
     if ((mode & 2) && (a.Cout2 % 32 || a.Cout2 > 64)) return hipErrorInvalidValue;
-    const int nw = c == 16 ? C2F_NW16 : c2f_nw32(mode);
-    c2f_fn fn = pick_c2f(c, mode, a.nk1);
+    const int nw = c == 16 ? C2F_NW16 : plan.nw;
+    if (c == 32 && nw != 8 && nw != 16) return hipErrorInvalidValue;
+    c2f_fn fn = pick_c2f(c, mode, a.nk1, nw);
     if (!fn || (mode == 2 && a.pair_in_co != 2 * c)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(fn, dim3((unsigned)plan.grid), dim3(nw * 64), (size_t)plan.lds_bytes, s, a);
     return hipGetLastError();

@@ -612,10 +612,10 @@ hipError_t nms_init()
 }
 
 hipError_t launch_nms(const Cand* cand, int* cand_count, int N, int n, float iou_thr, int nc,
-                      Cand* scratch, void* slabs, int cap, uint32_t tag0, hipStream_t s)
+                      Cand* scratch, void* slabs, int cap, uint32_t tag0, hipStream_t s, int force_general)
 {
     if (nc > NMS_MAX_CLASSES) return hipErrorInvalidValue;
-    static const int force_general = getenv("ZLY_NMS_GENERAL") != nullptr ? 1 : 0;     // tests / A-B: every frame on the eight-wave path
+    // force_general (ZLY_NMS_GENERAL, read per engine at zly_create): tests / A-B: every frame on the eight-wave path
     if (N > 4096 && g_nms_big_ok)
         hipLaunchKernelGGL(nms_kernel<2 * NMS_LDS_CAP>, dim3(n), dim3(NMS_THREADS), (size_t)2 * NMS_LDS_CAP * (sizeof(Cand) + 16), s, cand, cand_count, N, iou_thr, nc,
                            scratch, (unsigned char*)slabs, cap, tag0, force_general);

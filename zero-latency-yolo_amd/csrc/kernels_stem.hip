@@ -174,15 +174,42 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4s;
 
 __device__ __forceinline__ int div_small_s(int q, float inv) { return (int)(((float)q + 0.5f) * inv); }   // exact for q < 2^20, divisor < 2^10
 
-template <int NW>
+#ifdef ZLY_STEM_DIAG
+__device__ unsigned long long* g_stem_diag = nullptr;            // diagnostic build only (tools/stem_bench.hip): per-wave cycle sums of the phases
+#define STEMSTAMP(k) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); dsum[k] += t_ - dT0; dT0 = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define STEMSTAMP(k) do { } while (0)
+#endif
+
+// Tap order of the stem weights for VAR >= 1 (STEM1_TAP_SLOT[ky * 3 + kx] = k slot of 4 channels; k = slot * 4 + c, two k-steps of 32): the 8-byte
+// fragment halves of one ds_read_b64 -- lane groups kq 0/1 share the lanes 0-31, kq 2/3 the lanes 32-63 -- then hit disjoint banks.  A patch pixel is
+// 2 dwords and the 16 pixels of an MFMA tile are 2 pixels apart, so one lane group covers the banks = 0, 1 (mod 4) of its tap's offset; its partner must
+// read a tap an ODD number of pixels away (row pitch even: the parity of kx decides) or the very same addresses (zero-weight slots: broadcast).
+//   read 0 (k-step 0, first half):  kq0 (0,0)  kq1 (0,1)  kq2 (1,0)  kq3 (1,1)
+//   read 1 (k-step 0, second half): kq0 (2,0)  kq1 (2,1)  kq2 (0,2)  kq3 zero weights, reads kq2's pixel
+//   read 2 (k-step 1, first half):  kq0 (1,2)  kq1 zero   kq2 (2,2)  kq3 zero            (k-step 1, second half: all zero weights, not read)
+// Round 3's order (tap = s * 8 + kq * 2 + j) put two taps of equal pixel parity into half of the lane groups' pairs: 2-way conflicts on 4 of 8 half-wave
+// reads, and a fourth read for slots whose weights are all zero.
+static const int STEM1_TAP_SLOT[9] = {0, 2, 5, 4, 6, 8, 1, 3, 12};
+const int* stem1_tap_slot() { return STEM1_TAP_SLOT; }
+
+template <int NW, int VAR>
 __global__ __launch_bounds__(NW * 64, NW == 16 ? 8 : NW == 12 ? 6 : 4) void stem_model1_kernel(const Stem1Args a)
 {
+    constexpr bool NEWP = VAR >= 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem1[];
     const int RH = 2 * a.TH + 1, RW = 2 * a.TW + 1;          // stem pixels the tile needs
-    const int PH = 2 * RH + 1, PW = 2 * RW + 1;              // input pixels those need
+    const int PH = 2 * RH + 1, PWV = 2 * RW + 1;             // input pixels those need
+    // patch row pitch in pixels.  VAR >= 1: 4 TW + 6 = 2 (mod 4): rows are 16-byte aligned and consecutive rows are 16 bytes apart mod 32, which is what
+    // makes the staging stores below conflict-free; it is even, which the tap order above relies on
+    const int PW = NEWP ? PWV + 3 : PWV;
     unsigned char* lw = smem1;                               // model.1 weights: [2 tiles][9 taps][64 lanes][8 B]
     bf16x4* patch = reinterpret_cast<bf16x4*>(smem1 + 2 * 9 * 512);
     unsigned char* smap = reinterpret_cast<unsigned char*>(patch) + ((size_t)PH * PW * 8 + 15) / 16 * 16;
+#ifdef ZLY_STEM_DIAG
+    unsigned long long dsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dT0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long dstart = dT0;
+#endif
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -196,18 +223,85 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 8 : NW == 12 ? 6 : 4) void stem
     for (int u = tid; u < 2 * 9 * 512 / 16; u += NW * 64)
         *reinterpret_cast<u32x4s*>(lw + (size_t)u * 16) = *reinterpret_cast<const u32x4s*>(static_cast<const unsigned char*>(a.w1) + (size_t)u * 16);
 
-    const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(static_cast<const bf16_t*>(a.st.wgt) + lane * 8);
-    const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(static_cast<const bf16_t*>(a.st.wgt) + 512 + lane * 8);
+    const bf16_t* wg0 = static_cast<const bf16_t*>(NEWP ? a.wgt0p : a.st.wgt);
+    const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(wg0 + lane * 8);
+    const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(wg0 + 512 + lane * 8);
 
     // ---- 1. input patch ------------------------------------------------------------------------------------------
     const FrameDesc d = a.st.desc[f];
-    const float scale_w = (float)d.w / (float)a.st.tw;
-    const float scale_h = (float)d.h / (float)a.st.th;
     const uint8_t* src = a.st.src + d.src_off;
     const bool same = d.w == a.st.tw && d.h == a.st.th;
     const size_t frame_bytes = (size_t)d.w * d.h * 3;
-    const float invPW = 1.0f / (float)PW, invRW = 1.0f / (float)RW, invTW = 1.0f / (float)a.TW;
-    if (same) {
+    // VAR >= 1: the reciprocals come from the host (IEEE divides there give the same bits; six divides per thread were ~70 of a thread's ~630 VALU instructions)
+    const float invPW = NEWP ? a.inv_pw : 1.0f / (float)PWV, invRW = NEWP ? a.inv_rw : 1.0f / (float)RW, invTW = NEWP ? a.inv_tw : 1.0f / (float)a.TW;
+    STEMSTAMP(0);
+    if (same && NEWP) {
+        // Request size == model size (the metric's configuration): the resize map is the identity and a patch row is PWV * 3 contiguous bytes of the
+        // frame.  A thread takes FOUR consecutive pixels (a quad): one 12-byte load, v_cvt_f32_ubyte0..3 straight off the dwords, 12 multiplies, packed
+        // converts, TWO 16-byte LDS stores.  Lanes -> quads so that the stores are conflict-free (ds_write_b128 is served in groups of 8 consecutive
+        // lanes over 32 banks = eight 16-byte slots): the 8 lanes of a group take quads 4 qb .. 4 qb + 3 of patch rows 2 rp (lanes 0-3) and 2 rp + 1
+        // (lanes 4-7).  A quad is 32 bytes, so one row's four first halves fill slots 0, 2, 4, 6; the next row starts 16 bytes later mod 32
+        // (row pitch = 2 mod 4 pixels) and fills 1, 3, 5, 7.  (Round 3: consecutive lanes took consecutive quads with four 8-byte stores each, whose
+        // 16-lane groups hit 8 of 32 banks: 4-way conflicts, 62 % of this kernel's SQ_LDS_BANK_CONFLICT.)
+        const int QW = (PWV + 3) >> 2;                           // quads per patch row that hold pixels
+        const int QB = (QW + 3) >> 2;                            // blocks of four quads per row
+        const int NG = ((PH + 1) >> 1) * QB;                     // 8-lane groups = (row pair, quad block)
+        for (int u0 = 0; u0 < NG * 8; u0 += NW * 64 * 2) {
+            unsigned int r0[2][3];
+            int mode[2], pyq[2], pxq[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int u = u0 + k * NW * 64 + tid;
+                const int G = u >> 3;
+                mode[k] = 0;                                     // 0: nothing to do, 1: fast quad, 2: per-pixel quad
+                const int rp = div_small_s(G, a.inv_qb);
+                const int py = 2 * rp + ((u >> 2) & 1), q4 = (4 * (G - rp * QB) + (u & 3)) * 4;
+                if (G < NG && py < PH && q4 < PWV) {
+                    pyq[k] = py; pxq[k] = q4;
+                    const int iy = iy0 + py, ix = ix0 + q4;
+                    const bool row_in = (unsigned)iy < (unsigned)a.st.th;
+                    const bool fast = row_in && ix >= 0 && ix + 3 < a.st.tw && ((size_t)iy * d.w + ix) * 3 + 12 <= frame_bytes;    // the patch row has room for all four (pitch >= PWV + 3)
+                    mode[k] = fast ? 1 : 2;
+                    if (fast) {
+                        const uint8_t* q = src + ((size_t)iy * d.w + ix) * 3;
+                        typedef unsigned int u32x3 __attribute__((ext_vector_type(3), aligned(1)));
+                        const u32x3 v = *reinterpret_cast<const u32x3*>(q);          // 12 bytes: B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3 (unaligned global access is enabled on amdhsa)
+                        r0[k][0] = v[0]; r0[k][1] = v[1]; r0[k][2] = v[2];
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                if (mode[k] == 1) {
+                    const float kk = 1.0f / 255.0f;              // bf16(u8 * (1/255.f)) == bf16(u8 / 255.f) for all 256 values (tests/test_model_spec.py)
+                    const unsigned int x0 = r0[k][0], x1 = r0[k][1], x2 = r0[k][2];
+                    const float b0 = (float)(x0 & 0xffu) * kk, g0 = (float)((x0 >> 8) & 0xffu) * kk, rr0 = (float)((x0 >> 16) & 0xffu) * kk;
+                    const float b1 = (float)(x0 >> 24) * kk, g1 = (float)(x1 & 0xffu) * kk, rr1 = (float)((x1 >> 8) & 0xffu) * kk;
+                    const float b2 = (float)((x1 >> 16) & 0xffu) * kk, g2 = (float)(x1 >> 24) * kk, rr2 = (float)(x2 & 0xffu) * kk;
+                    const float b3 = (float)((x2 >> 8) & 0xffu) * kk, g3 = (float)((x2 >> 16) & 0xffu) * kk, rr3 = (float)(x2 >> 24) * kk;
+                    bf16x8 lo, hi;
+                    lo[0] = (bf16_t)rr0; lo[1] = (bf16_t)g0; lo[2] = (bf16_t)b0; lo[3] = (bf16_t)0.f; lo[4] = (bf16_t)rr1; lo[5] = (bf16_t)g1; lo[6] = (bf16_t)b1; lo[7] = (bf16_t)0.f;
+                    hi[0] = (bf16_t)rr2; hi[1] = (bf16_t)g2; hi[2] = (bf16_t)b2; hi[3] = (bf16_t)0.f; hi[4] = (bf16_t)rr3; hi[5] = (bf16_t)g3; hi[6] = (bf16_t)b3; hi[7] = (bf16_t)0.f;
+                    bf16x8* dst = reinterpret_cast<bf16x8*>(patch + pyq[k] * PW + pxq[k]);      // 32-byte aligned: rows are 16-byte aligned (PW even), quads 32 bytes
+                    dst[0] = lo;
+                    dst[1] = hi;
+                } else if (mode[k] == 2) {
+                    for (int j = 0; j < 4; ++j) {
+                        const int pxx = pxq[k] + j;
+                        if (pxx >= PWV) break;
+                        const int iy = iy0 + pyq[k], ix = ix0 + pxx;
+                        bf16x4 v = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+                        if ((unsigned)iy < (unsigned)a.st.th && (unsigned)ix < (unsigned)a.st.tw) {
+                            const uint8_t* q = src + ((size_t)iy * d.w + ix) * 3;
+                            const float kk = 1.0f / 255.0f;
+                            v[0] = (bf16_t)((float)q[2] * kk); v[1] = (bf16_t)((float)q[1] * kk); v[2] = (bf16_t)((float)q[0] * kk);
+                        }
+                        patch[pyq[k] * PW + pxx] = v;
+                    }
+                }
+            }
+        }
+    } else if (same) {
         // Request size == model size (the metric's configuration): the resize map is the identity and a patch row is PW * 3 contiguous
         // bytes of the frame.  A thread takes FOUR consecutive pixels: one 12-byte load, v_cvt_f32_ubyte0..3 straight off the dwords, 12
         // multiplies, packed converts, two 16-byte LDS stores -- ~9 VALU per pixel.  (The general path below spends ~40 per pixel on the
@@ -273,13 +367,15 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 8 : NW == 12 ? 6 : 4) void stem
     } else {
         // all of a thread's loads are issued before the first conversion (the loop below is fully unrolled: STEM1_MAXIT pixels per thread):
         // with one load per loop iteration every iteration exposed a full memory round trip, ~6 us of the ~12 us a tile took
+        const float scale_w = (float)d.w / (float)a.st.tw;
+        const float scale_h = (float)d.h / (float)a.st.th;
         unsigned int raw[STEM1_MAXIT];
     #pragma unroll
         for (int k = 0; k < STEM1_MAXIT; ++k) {
             const int u = tid + k * NW * 64;
             raw[k] = 0x80000000u;                                   // bit 31: pixel outside the model-sized image (or beyond the patch) -> zeros
-            if (u < PH * PW) {
-                const int py = div_small_s(u, invPW), px = u - py * PW;
+            if (u < PH * PWV) {
+                const int py = div_small_s(u, invPW), px = u - py * PWV;
                 const int iy = iy0 + py, ix = ix0 + px;
                 if ((unsigned)iy < (unsigned)a.st.th && (unsigned)ix < (unsigned)a.st.tw) {
                     int sy = iy, sx = ix;
@@ -299,28 +395,39 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 8 : NW == 12 ? 6 : 4) void stem
     #pragma unroll
         for (int k = 0; k < STEM1_MAXIT; ++k) {
             const int u = tid + k * NW * 64;
-            if (u < PH * PW) {
+            if (u < PH * PWV) {
                 bf16x4 v = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
                 if (!(raw[k] & 0x80000000u)) {
                     const float kk = 1.0f / 255.0f;                  // bf16(u8 * (1/255.f)) == bf16(u8 / 255.f) for all 256 values (tests/test_model_spec.py)
                     v[0] = (bf16_t)((float)((raw[k] >> 16) & 0xffu) * kk); v[1] = (bf16_t)((float)((raw[k] >> 8) & 0xffu) * kk); v[2] = (bf16_t)((float)(raw[k] & 0xffu) * kk);
                 }
-                patch[u] = v;
+                const int py = div_small_s(u, invPW);
+                patch[u + py * (PW - PWV)] = v;
             }
         }
     }
+    STEMSTAMP(1);
     __syncthreads();
+    STEMSTAMP(2);
 
     // ---- 2. stem conv over the region -> LDS map ---------------------------------------------------------------------
     int toff[2][2];
+    if (NEWP) {
+        // STEM1_TAP_SLOT's order (above): reads 0 / 1 are the halves of k-step 0, read 2 the first half of k-step 1; k-step 1's second half is zero
+        const int ky0 = kq >> 1, kx0 = kq & 1;                                                          // (0,0) (0,1) (1,0) (1,1)
+        const int ky1 = kq < 2 ? 2 : 0, kx1 = kq < 2 ? kq : 2;                                          // (2,0) (2,1) (0,2) (0,2)
+        const int ky2 = kq < 2 ? 1 : 2;                                                                 // (1,2) (1,2) (2,2) (2,2)
+        toff[0][0] = ky0 * PW + kx0; toff[0][1] = ky1 * PW + kx1; toff[1][0] = ky2 * PW + 2; toff[1][1] = 0;
+    } else {
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+        for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int tap = s * 8 + kq * 2 + j;                 // taps >= 9 have zero weights: read any valid pixel
-            const int ky = tap < 9 ? tap / 3 : 0, kx = tap < 9 ? tap - (tap / 3) * 3 : 0;
-            toff[s][j] = ky * PW + kx;
-        }
+            for (int j = 0; j < 2; ++j) {
+                const int tap = s * 8 + kq * 2 + j;                 // taps >= 9 have zero weights: read any valid pixel
+                const int ky = tap < 9 ? tap / 3 : 0, kx = tap < 9 ? tap - (tap / 3) * 3 : 0;
+                toff[s][j] = ky * PW + kx;
+            }
+    }
     const f32x4 bias0 = *reinterpret_cast<const f32x4*>(a.st.bias + kq * 4);
     const int NR = RH * RW, ntR = (NR + 15) >> 4;
     // One 16-pixel tile of the region: fragments -> 2 MFMAs -> bias + SiLU -> LDS map.  Lanes beyond the region's last pixel work on a copy of
@@ -334,7 +441,8 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 8 : NW == 12 ? 6 : 4) void stem
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const bf16x4 lo = patch[base + toff[s][0]];
-            const bf16x4 hi = patch[base + toff[s][1]];
+            bf16x4 hi = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+            if (!(NEWP && s == 1)) hi = patch[base + toff[s][1]];
             af[s][0] = lo[0]; af[s][1] = lo[1]; af[s][2] = lo[2]; af[s][3] = lo[3];
             af[s][4] = hi[0]; af[s][5] = hi[1]; af[s][6] = hi[2]; af[s][7] = hi[3];
         }
@@ -391,7 +499,9 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 8 : NW == 12 ? 6 : 4) void stem
     };
     if (sy0 >= 0 && sx0 >= 0 && sy0 + RH <= a.st.Ho && sx0 + RW <= a.st.Wo) phase2(std::false_type{});
     else phase2(std::true_type{});
+    STEMSTAMP(3);
     __syncthreads();
+    STEMSTAMP(4);
 
     // ---- 3. model.1 (3x3 s2, 16 -> 32) from the LDS map --------------------------------------------------------------------
     f32x4 b1lo = *reinterpret_cast<const f32x4*>(a.b1 + kq * 8), b1hi = *reinterpret_cast<const f32x4*>(a.b1 + kq * 8 + 4);
@@ -453,13 +563,20 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 8 : NW == 12 ? 6 : 4) void stem
         m1_tile(t3, a0, a1, oyA, oxA);
         m1_finish(t3, a0, a1, oyA, oxA);
     }
+    STEMSTAMP(5);
+#ifdef ZLY_STEM_DIAG
+    if (lane == 0 && g_stem_diag) {
+        unsigned long long* o = g_stem_diag + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * NW + wave) * 8;
+        for (int i = 0; i < 6; ++i) o[i] = dsum[i];
+        o[6] = __builtin_amdgcn_s_memtime() - dstart;
+    }
+#endif
 }
 
 static constexpr int STEM1_NW = 8;
-static int stem1_nw() { static const int v = getenv("ZLY_STEM1_NW") ? atoi(getenv("ZLY_STEM1_NW")) : STEM1_NW; return (v == 12 || v == 16) ? v : STEM1_NW; }     // tuning aid
-static size_t stem1_lds_bytes(int th, int tw)
+static size_t stem1_lds_bytes(int th, int tw, int var)
 {
-    const size_t RH = 2 * th + 1, RW = 2 * tw + 1, PH = 2 * RH + 1, PW = 2 * RW + 1;
+    const size_t RH = 2 * th + 1, RW = 2 * tw + 1, PH = 2 * RH + 1, PW = 2 * RW + 1 + (var >= 1 ? 3 : 0);
     return 2 * 9 * 512 + (PH * PW * 8 + 15) / 16 * 16 + RH * RW * STEM1_PITCH;
 }
 
@@ -475,25 +592,37 @@ void stem1_plan(int H1, int W1, int* th, int* tw)
     (void)H1;
 }
 
-hipError_t stem1_init()
+typedef void (*stem1_fn)(const Stem1Args);
+static stem1_fn pick_stem1(int nw, int var)
 {
-    hipError_t r = hipFuncSetAttribute((const void*)stem_model1_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (r != hipSuccess) return r;
-    r = hipFuncSetAttribute((const void*)stem_model1_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (r != hipSuccess) return r;
-    return hipFuncSetAttribute((const void*)stem_model1_kernel<STEM1_NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (var >= 1) return nw == 12 ? stem_model1_kernel<12, 1> : nw == 16 ? stem_model1_kernel<16, 1> : stem_model1_kernel<STEM1_NW, 1>;
+    return nw == 12 ? stem_model1_kernel<12, 0> : nw == 16 ? stem_model1_kernel<16, 0> : stem_model1_kernel<STEM1_NW, 0>;
 }
 
-hipError_t launch_stem_model1(const Stem1Args& a, int n, hipStream_t s)
+hipError_t stem1_init()
 {
+    for (int var = 0; var <= 1; ++var)
+        for (int nw : {STEM1_NW, 12, 16}) {
+            hipError_t r = hipFuncSetAttribute((const void*)pick_stem1(nw, var), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (r != hipSuccess) return r;
+        }
+    return hipSuccess;
+}
+
+// a.nw: waves per workgroup (8; 12 / 16 = tuning aid ZLY_STEM1_NW), a.var: 1 = conflict-free staging and tap order (default), 0 = round 3's (ZLY_STEM1_VAR=0);
+// both are read by the engine once per zly_create, not here (a process-static switch cannot be toggled by a test)
+hipError_t launch_stem_model1(const Stem1Args& a0, int n, hipStream_t s)
+{
+    Stem1Args a = a0;
     if (a.st.Cout != 16 || a.TH < 1 || a.TW < 1 || a.out1_cs % 8 || a.out1_co % 8) return hipErrorInvalidValue;
     if (a.H1 * 2 != a.st.Ho || a.W1 * 2 != a.st.Wo) return hipErrorInvalidValue;      // even stem map: model.1 output = half of it
-    const size_t lds = stem1_lds_bytes(a.TH, a.TW);
+    const int nw = (a.nw == 12 || a.nw == 16) ? a.nw : STEM1_NW, var = a.var >= 1 ? 1 : 0;
+    if (var >= 1 && !a.wgt0p) return hipErrorInvalidValue;
+    const size_t lds = stem1_lds_bytes(a.TH, a.TW, var);
     if (lds > 160 * 1024 || (4 * a.TH + 3) * (4 * a.TW + 3) > STEM1_MAXIT * STEM1_NW * 64) return hipErrorInvalidValue;
-    const int nw = stem1_nw();
-    if (nw == 12) hipLaunchKernelGGL(stem_model1_kernel<12>, dim3(a.tiles_x * a.tiles_y, n), dim3(12 * 64), lds, s, a);
-    else if (nw == 16) hipLaunchKernelGGL(stem_model1_kernel<16>, dim3(a.tiles_x * a.tiles_y, n), dim3(16 * 64), lds, s, a);
-    else hipLaunchKernelGGL(stem_model1_kernel<STEM1_NW>, dim3(a.tiles_x * a.tiles_y, n), dim3(STEM1_NW * 64), lds, s, a);
+    const int pwv = 4 * a.TW + 3, qb = ((pwv + 3) / 4 + 3) / 4;
+    a.inv_pw = 1.0f / (float)pwv; a.inv_rw = 1.0f / (float)(2 * a.TW + 1); a.inv_tw = 1.0f / (float)a.TW; a.inv_qb = 1.0f / (float)qb;
+    hipLaunchKernelGGL(pick_stem1(nw, var), dim3(a.tiles_x * a.tiles_y, n), dim3(nw * 64), lds, s, a);
     return hipGetLastError();
 }
 

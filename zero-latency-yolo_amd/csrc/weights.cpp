@@ -2,6 +2,7 @@
 // tools/zly_model.py; it stands in for the .onnx file the reference loads in loadModel
 // (reference src/inference/onnx_engine.cpp:957-1062).
 #include "weights.h"
+#include <algorithm>
 #include "zly.h"
 
 #include <math.h>
@@ -124,13 +125,15 @@ uint16_t f32_to_bf16_rne(float f)
 
 void repack_conv(const std::vector<const ConvRec*>& srcs, int cin_store, int kstep, bool bf16,
                  std::vector<uint8_t>* w_out, std::vector<float>* bias_out, int* cout_total, int* cout_pad, int* nk,
-                 bool pair_rows, int epl_override)
+                 bool pair_rows, int epl_override, const int* tap_slot)
 {
     const int ks = srcs[0]->k, cin = srcs[0]->cin;
+    int nslots = ks * ks;
+    if (tap_slot) for (int t = 0; t < ks * ks; ++t) nslots = std::max(nslots, tap_slot[t] + 1);
     int ctot = 0;
     for (const ConvRec* s : srcs) ctot += s->cout;
     const int cpad = (ctot + 15) / 16 * 16;
-    const int K = ks * ks * cin_store;
+    const int K = nslots * cin_store;
     const int nkk = (K + kstep - 1) / kstep;
     const size_t esz = bf16 ? 2 : 4;
     const int epl = epl_override > 0 ? epl_override : 16 / (int)esz;   // k values one lane feeds per k-step (one 16-byte fragment by default)
@@ -153,7 +156,7 @@ void repack_conv(const std::vector<const ConvRec*>& srcs, int cin_store, int kst
             for (int ky = 0; ky < ks; ++ky)
                 for (int kx = 0; kx < ks; ++kx)
                     for (int ci = 0; ci < cin; ++ci) {
-                        const int k = (ky * ks + kx) * cin_store + ci;
+                        const int k = (tap_slot ? tap_slot[ky * ks + kx] : ky * ks + kx) * cin_store + ci;
                         const int st = k / kstep, kk = k % kstep;
                         // 1 KiB tile in MFMA lane order: lane = (kk / epl) * 16 + r holds epl consecutive k
                         const size_t dst = ((size_t)ct * nkk + st) * 16 * kstep + ((size_t)(kk / epl) * 16 + r) * epl + kk % epl;

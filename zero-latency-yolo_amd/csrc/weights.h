@@ -37,6 +37,7 @@ float fp8_e4m3_to_f32(uint8_t v);
 // 8-channel tensor for its 3 input channels).  bf16 -> 2-byte elements, else fp32.
 void repack_conv(const std::vector<const ConvRec*>& srcs, int cin_store, int kstep, bool bf16,
                  std::vector<uint8_t>* w_out, std::vector<float>* bias_out, int* cout_total, int* cout_pad, int* nk,
-                 bool pair_rows = false, int epl_override = 0);   // epl_override: k values per lane and k-step (4 for the 16x16x16 MFMA)
+                 bool pair_rows = false, int epl_override = 0,    // epl_override: k values per lane and k-step (4 for the 16x16x16 MFMA)
+                 const int* tap_slot = nullptr);                  // optional [ks*ks]: tap (ky*ks + kx) takes k positions [slot*cin_store, +cin) instead of [tap*cin_store, +cin)
 
 }  // namespace zly

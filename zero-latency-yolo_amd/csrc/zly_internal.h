@@ -40,7 +40,7 @@ struct ConvArgs {
     const void* in2;  int in2_cs, in2_co, split_c;
 };
 
-struct ConvLaunch { int ks, ct, pt, fastk, ksplit, lds, stream, wres, ps, ws1; };
+struct ConvLaunch { int ks, ct, pt, fastk, ksplit, lds, stream, wres, ps, ws1, rowt; };   // rowt: weight-stationary 3x3 kernel's row-tile form (ZLY_WS_ROWT, read when the shape is picked)
 struct ConvArgsMulti { ConvArgs a[6]; int n; };       // independent convs of one launch (conv_igemm_multi_kernel)
 hipError_t launch_conv_multi(const ConvArgsMulti& m, int ct, hipStream_t s);
 
@@ -88,7 +88,7 @@ struct C2fArgs {
     int dump;                                 // also write the intermediates that would stay in LDS to cat (debug taps)
     void* mid; int mid_cs;                    // c = 64 with dump: the bottleneck's intermediate map (its first conv's output buffer of the unfused path)
 };
-struct C2fPlan { int th, tw, tiles_x, tiles_y, total_tiles, grid, lds_bytes; };
+struct C2fPlan { int th, tw, tiles_x, tiles_y, total_tiles, grid, lds_bytes, nw; };      // nw: waves per workgroup the plan was made for
 bool       c2f_plan(int c, int mode, int nk1, int nk2, int cout2, int n, int H, int W, C2fPlan* plan);
 hipError_t c2f_init();
 hipError_t launch_c2f(int c, int mode, const C2fArgs& a, const C2fPlan& plan, hipStream_t s);
@@ -121,10 +121,15 @@ struct Stem1Args {
     int H1, W1;                               // model.1 output map
     int TH, TW, tiles_x, tiles_y;
     int dump;
+    int nw, var;                              // waves per workgroup (0 = default), kernel variant (1 = conflict-free staging / tap order, 0 = round 3's)
+    // set by launch_stem_model1 (host IEEE divides: the kernel used to spend six fp32 divides per thread on them)
+    float inv_pw, inv_rw, inv_tw, inv_qb;     // 1 / patch row pitch, 1 / region width, 1 / tile width, 1 / quad blocks per patch row
+    const void* wgt0p;                        // stem weights in the tap order of the conflict-free fragment reads (kernels_stem.hip: STEM1_TAP_SLOT)
 };
 void       stem1_plan(int H1, int W1, int* th, int* tw);
 hipError_t stem1_init();
 hipError_t launch_stem_model1(const Stem1Args& a, int n, hipStream_t s);
+const int* stem1_tap_slot();              // [9]: k slot of tap ky * 3 + kx in Stem1Args::wgt0p (weights.h: repack_conv's tap_slot)
 
 // kernels_head.hip -- fused Detect head (final 1x1 convs + DFL + dist2bbox + sigmoid + decode/threshold)
 struct HeadLevel {
@@ -136,6 +141,7 @@ struct HeadLevel {
     int H, W, hw, stride_px, anchor_off, block0;
     float* logits; int logits_cs;             // optional fp32 [n][H*W][logits_cs] dump (debug taps), or null
 };
+#define HEAD_KMAX 8                           // most k-steps of one Detect branch the fused tail holds in registers (bf16: 256 channels, fp32: 128)
 #define HEAD_WAVES 8                          // waves per workgroup of the fused Detect tail, one 16-anchor tile each
 #define HEAD_GROUP (HEAD_WAVES * 16)          // anchors per workgroup; HeadLevel::block0 / total_blocks count these groups
 struct HeadArgs {
@@ -156,6 +162,6 @@ hipError_t launch_decode(const float* head, int nc, int N, int n, const FrameDes
                          Cand* cand, int* cand_count, hipStream_t s);
 hipError_t nms_init();
 hipError_t launch_nms(const Cand* cand, int* cand_count, int N, int n, float iou_thr, int nc,
-                      Cand* scratch, void* slabs, int cap, uint32_t tag0, hipStream_t s);
+                      Cand* scratch, void* slabs, int cap, uint32_t tag0, hipStream_t s, int force_general = 0);
 
 }  // namespace zly

@@ -9,6 +9,7 @@
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <random>
 
 namespace zero_latency {
 
@@ -40,6 +41,7 @@ int envInt(const char* name, int fallback)
 
 struct HipInferenceEngine::EngineHandle {
     zly_engine* e = nullptr;
+    std::atomic<bool> replaced{false};                   // set by reloadModel / shutdown when the handle leaves engines_: its last request hands it to the reaper
     explicit EngineHandle(zly_engine* p) : e(p) {}
     ~EngineHandle() { if (e) zly_destroy(e); }
     EngineHandle(const EngineHandle&) = delete;
@@ -57,7 +59,8 @@ HipInferenceEngine::~HipInferenceEngine() { shutdown(); }
 Result<void> HipInferenceEngine::initialize()
 {
     if (running_) return Result<void>::ok();
-    const int ndev = std::max(1, envInt("ZLY_NUM_DEVICES", 1));
+    simulate_ = envInt("ZLY_SIMULATE", 0) != 0;               // explicit opt-in only: a missing or bad model file is an ERROR below, never a silent fake
+    const int ndev = simulate_ ? 0 : std::max(1, envInt("ZLY_NUM_DEVICES", 1));
     const int dev0 = std::max(0, envInt("ZLY_FIRST_DEVICE", 0));
     first_device_ = dev0;
     // ZLY_ENGINES_PER_GPU (default 2): several engine instances per GPU, each one chain of launches on its own stream; consecutive
@@ -76,16 +79,25 @@ Result<void> HipInferenceEngine::initialize()
     {
         std::lock_guard<std::mutex> lk(engines_mutex_);
         engines_ = std::move(fresh);
+        std::atomic_store(&engines_snapshot_, std::make_shared<const std::vector<std::shared_ptr<EngineHandle>>>(engines_));
     }
     {
         std::lock_guard<std::mutex> lk(stats_mutex_);
-        model_hash_ = sha256File(config_.model_path);
+        model_hash_ = simulate_ ? std::string() : sha256File(config_.model_path);
+    }
+    if (simulate_) {
+        // std::random_device like the reference (:1137-1138), or a fixed seed for tests (ZLY_SIMULATE_SEED)
+        std::random_device rd;
+        const int seed = envInt("ZLY_SIMULATE_SEED", -1);
+        for (int i = 0; i < 4; ++i) sim_rng_state_[i] = seed >= 0 ? (uint32_t)seed * 2654435761u + (uint32_t)i : rd();
     }
     model_version_ = 1;
     {
         std::lock_guard<std::mutex> lk(queue_mutex_);
         pending_.clear();                                      // nothing of a previous run may be emitted under the new sequence numbers
-        finished_.clear();
+        ring_.assign(1024, Done{});
+        ring_full_.assign(1024, 0);
+        finished_count_ = 0;
         next_seq_ = 0;
         next_emit_ = 0;
     }
@@ -96,7 +108,7 @@ Result<void> HipInferenceEngine::initialize()
     }
     reaper_ = std::thread(&HipInferenceEngine::reaperLoop, this);
     completer_ = std::thread(&HipInferenceEngine::completionLoop, this);
-    if (envInt("ZLY_MODEL_WATCH_MS", 10000) > 0) monitor_ = std::thread(&HipInferenceEngine::monitorLoop, this);
+    if (!simulate_ && envInt("ZLY_MODEL_WATCH_MS", 10000) > 0) monitor_ = std::thread(&HipInferenceEngine::monitorLoop, this);
     return Result<void>::ok();
 }
 
@@ -129,6 +141,7 @@ std::shared_ptr<HipInferenceEngine::EngineHandle> HipInferenceEngine::createEngi
 Result<void> HipInferenceEngine::reloadModel()
 {
     if (!running_) return Result<void>::error(ErrorCode::NOT_INITIALIZED, "Engine not running");
+    if (simulate_) return Result<void>::error(ErrorCode::INVALID_ARGUMENT, "simulation mode has no model to reload");
     std::lock_guard<std::mutex> rl(reload_mutex_);
     const std::string hash = sha256File(config_.model_path);
     size_t count;
@@ -147,8 +160,9 @@ Result<void> HipInferenceEngine::reloadModel()
     {
         std::lock_guard<std::mutex> lk(engines_mutex_);
         engines_.swap(fresh);
+        std::atomic_store(&engines_snapshot_, std::make_shared<const std::vector<std::shared_ptr<EngineHandle>>>(engines_));
     }
-    for (auto& h : fresh) retire(std::move(h));                 // old engines go -- on the reaper thread -- when their last pending request is done
+    for (auto& h : fresh) { h->replaced = true; retire(std::move(h)); }     // old engines go -- on the reaper thread -- when their last pending request is done
     fresh.clear();
     {
         std::lock_guard<std::mutex> lk(stats_mutex_);
@@ -158,28 +172,42 @@ Result<void> HipInferenceEngine::reloadModel()
     return Result<void>::ok();
 }
 
+// Engines replaced by a hot reload: the reaper takes a reference of each and KEEPS it until it is the only one left (requests in flight on the old
+// engine hold the others), then runs zly_destroy -- on its own thread, never on the completion thread or a submitting thread.
 void HipInferenceEngine::retire(std::shared_ptr<EngineHandle>&& h)
 {
     if (!h) return;
-    const bool last = h.use_count() == 1;
     {
         std::lock_guard<std::mutex> lk(reap_mutex_);
         retired_.push_back(std::move(h));
     }
-    if (last) reap_cv_.notify_one();                            // otherwise the reaper's next periodic pass drops it
+    reap_cv_.notify_one();
 }
+
+// A finished request lets go of its engine.  That is an atomic decrement and never the last reference: engines_ holds one while the engine serves, the
+// reaper holds one from the moment a reload replaces it until every request has let go.  (Round 3 pushed EVERY frame's reference through reap_mutex_
+// and the reaper's vector.)
+void HipInferenceEngine::release(std::shared_ptr<EngineHandle>&& h) { h.reset(); }
 
 void HipInferenceEngine::reaperLoop()
 {
-    std::vector<std::shared_ptr<EngineHandle>> batch;
+    std::vector<std::shared_ptr<EngineHandle>> mine, dead;
     while (true) {
+        bool stop;
         {
             std::unique_lock<std::mutex> lk(reap_mutex_);
-            reap_cv_.wait_for(lk, std::chrono::milliseconds(50), [&] { return reap_stop_ || !retired_.empty(); });
-            batch.swap(retired_);
-            if (batch.empty() && reap_stop_) return;
+            reap_cv_.wait_for(lk, std::chrono::milliseconds(mine.empty() ? 50 : 5), [&] { return reap_stop_ || !retired_.empty(); });
+            for (auto& h : retired_) mine.push_back(std::move(h));
+            retired_.clear();
+            stop = reap_stop_;
         }
-        batch.clear();                                          // the last reference of a replaced engine: zly_destroy runs here
+        // sole owner = the last request on that engine has been delivered: destroy it here.  At shutdown the completion thread has been joined already;
+        // what is still referenced elsewhere (requests dropped by shutdown) is let go and dies with its last reference on the shutting-down thread.
+        for (auto& h : mine)
+            if (stop || h.use_count() == 1) dead.push_back(std::move(h));
+        mine.erase(std::remove(mine.begin(), mine.end(), nullptr), mine.end());
+        dead.clear();                                           // zly_destroy runs here
+        if (stop) return;
     }
 }
 
@@ -230,12 +258,13 @@ Result<void> HipInferenceEngine::shutdown()
         std::lock_guard<std::mutex> lk(queue_mutex_);
         dropped_frames_ += pending_.size();
         pending_.clear();                                       // stale results must never be emitted by a later initialize()
-        finished_.clear();
+        ring_.clear(); ring_full_.clear(); finished_count_ = 0;
     }
     std::vector<std::shared_ptr<EngineHandle>> old;
     {
         std::lock_guard<std::mutex> lk(engines_mutex_);
         old.swap(engines_);
+        std::atomic_store(&engines_snapshot_, std::shared_ptr<const std::vector<std::shared_ptr<EngineHandle>>>());
     }
     old.clear();
     return Result<void>::ok();
@@ -251,24 +280,30 @@ Result<void> HipInferenceEngine::submitInference(const InferenceRequest& request
     p.seq = seq;
     p.client_id = request.client_id; p.frame_id = request.frame_id; p.timestamp = request.timestamp;
     p.enqueue_ms = wallMs();
-    {
-        std::lock_guard<std::mutex> lk(engines_mutex_);
-        if (!engines_.empty()) p.engine = engines_[(size_t)(seq % engines_.size())];        // one-frame-per-engine round robin
-    }
-    if (!p.engine) {
-        p.failed = true;
+    if (simulate_) {
+        // the reference's simulation mode checks nothing about the frame (runInference, :524-528)
+        p.simulated = true;
     } else {
-        // a request with the wrong byte count fails alone (INVALID_INPUT, onnx_engine.cpp:659-665): counted, no callback
-        const int32_t rc = zly_submit(p.engine->e, request.data.data(), request.data.size(), request.width, request.height, &p.ticket);
-        if (rc != ZLY_OK) { p.failed = true; p.engine.reset(); }
+        const auto snap = std::atomic_load(&engines_snapshot_);                           // immutable snapshot: no lock shared by the submitting threads
+        if (snap && !snap->empty()) p.engine = (*snap)[(size_t)(seq % snap->size())];     // one-frame-per-engine round robin
+        if (!p.engine) {
+            p.failed = true;
+        } else {
+            // a request with the wrong byte count fails alone (INVALID_INPUT, onnx_engine.cpp:659-665): counted, no callback
+            const int32_t rc = zly_submit(p.engine->e, request.data.data(), request.data.size(), request.width, request.height, &p.ticket);
+            if (rc != ZLY_OK) { p.failed = true; p.engine.reset(); }
+        }
+        if (p.failed) inference_errors_++;
     }
-    if (p.failed) inference_errors_++;
+    bool wake;
     {
         std::lock_guard<std::mutex> lk(queue_mutex_);
+        wake = pending_.empty();                                 // the completion thread only sleeps on an empty queue
         pending_.push_back(std::move(p));
-        if (pending_.size() + finished_.size() > queue_high_water_mark_) queue_high_water_mark_ = pending_.size() + finished_.size();
+        const size_t depth = pending_.size() + finished_count_;
+        if (depth > queue_high_water_mark_) queue_high_water_mark_ = depth;
     }
-    queue_cv_.notify_one();
+    if (wake) queue_cv_.notify_one();
     return Result<void>::ok();
 }
 
@@ -281,69 +316,128 @@ void HipInferenceEngine::setCallback(InferenceCallback callback)
 size_t HipInferenceEngine::getQueueSize() const
 {
     std::lock_guard<std::mutex> lk(queue_mutex_);
-    return pending_.size() + finished_.size();
+    return pending_.size() + finished_count_;
 }
 
 std::string HipInferenceEngine::getName() const { return "hip"; }
 
+// generateRandomDetections of the reference's simulation mode (onnx_engine.cpp:1133-1177), ZLY_SIMULATE=1 only: 0-5 detections, centre in [0.1, 0.9],
+// width in [0.05, 0.2], height = 1.5 x a second draw from that range, confidence in [0.6, 1.0], class in 0..3, track_id = i + 1, timestamp = now (ms).
+std::vector<Detection> HipInferenceEngine::generateRandomDetections()
+{
+    auto next = [this]() {                                       // xoshiro128**: small, seedable state owned by the completion thread
+        uint32_t* st = sim_rng_state_;
+        const uint32_t x = st[1] * 5u, r = ((x << 7) | (x >> 25)) * 9u, t = st[1] << 9;
+        st[2] ^= st[0]; st[3] ^= st[1]; st[1] ^= st[2]; st[0] ^= st[3]; st[2] ^= t; st[3] = (st[3] << 11) | (st[3] >> 21);
+        return r;
+    };
+    auto uni = [&](double lo, double hi) { return lo + (hi - lo) * ((double)(next() >> 8) * (1.0 / 16777216.0)); };
+    std::vector<Detection> out((size_t)(next() % 6u));
+    const uint64_t now = wallMs();
+    for (size_t i = 0; i < out.size(); ++i) {
+        Detection& d = out[i];
+        d.box.x = (float)uni(0.1, 0.9); d.box.y = (float)uni(0.1, 0.9);
+        d.box.width = (float)uni(0.05, 0.2); d.box.height = (float)uni(0.05, 0.2) * 1.5f;
+        d.confidence = (float)uni(0.6, 1.0);
+        d.class_id = (int)(next() % 4u);
+        d.track_id = (uint32_t)i + 1;
+        d.timestamp = now;
+    }
+    return out;
+}
+
 // One engine-owned thread hands results to the callback in submission order (reference: the inference thread,
 // onnx_engine.cpp:355-364); several GPUs finishing out of order are re-ordered by the sequence number.
+// Per wake-up it takes EVERYTHING that is pending (one lock), blocks for the first ticket and then collects, without blocking, every following
+// ticket whose batch is back as well (zly_poll): a device batch of 64 frames costs two lock acquisitions on queue_mutex_ and one on stats_mutex_,
+// where round 3 paid two + one per FRAME against twelve submitting threads on the same mutex.
 void HipInferenceEngine::completionLoop()
 {
     std::vector<zly_det> dets((size_t)max_dets_);
+    std::deque<Pending> local;
+    std::vector<std::pair<uint64_t, Done>> group;               // (sequence number, result) of the frames completed in this round
+    std::vector<Done> ready;
     while (true) {
-        Pending p;
-        {
+        if (local.empty()) {
             std::unique_lock<std::mutex> lk(queue_mutex_);
             queue_cv_.wait_for(lk, std::chrono::milliseconds(100), [&] { return !pending_.empty() || !running_; });
             if (pending_.empty()) {
                 if (!running_) return;                           // shutting down: everything already in the ring has been handed over
                 continue;
             }
-            p = std::move(pending_.front());
-            pending_.pop_front();
+            local.swap(pending_);
         }
-        Done d;
-        d.client_id = p.client_id; d.enqueue_ms = p.enqueue_ms;
-        if (!p.failed) {
-            int32_t n = 0;
-            const int32_t rc = zly_wait(p.engine->e, p.ticket, dets.data(), max_dets_, &n);
-            if (rc == ZLY_OK) {
+        group.clear();
+        bool first = true;
+        while (!local.empty()) {
+            Pending& p = local.front();
+            // the first request of a round may block for its batch; the ones behind it are taken only if their batch is back too
+            if (!first && !p.failed && !p.simulated && zly_poll(p.engine->e, p.ticket) != ZLY_OK) break;
+            first = false;
+            Done d;
+            d.client_id = p.client_id; d.enqueue_ms = p.enqueue_ms;
+            if (p.simulated) {
                 d.ok = true;
-                d.state.frame_id = p.frame_id;                   // onnx_engine.cpp:520-521
-                d.state.timestamp = p.timestamp;
-                const int cnt = std::min<int>(n, max_dets_);
-                d.state.detections.resize((size_t)cnt);
-                static_assert(sizeof(zly_det) == sizeof(Detection), "zly_det must be layout-identical to Detection");
-                if (cnt) std::memcpy(d.state.detections.data(), dets.data(), (size_t)cnt * sizeof(Detection));
-            } else {
-                inference_errors_++;
+                d.state.frame_id = p.frame_id; d.state.timestamp = p.timestamp;
+                d.state.detections = generateRandomDetections();
+            } else if (!p.failed) {
+                int32_t n = 0;
+                const int32_t rc = zly_wait(p.engine->e, p.ticket, dets.data(), max_dets_, &n);
+                if (rc == ZLY_OK) {
+                    d.ok = true;
+                    d.state.frame_id = p.frame_id;               // onnx_engine.cpp:520-521
+                    d.state.timestamp = p.timestamp;
+                    const int cnt = std::min<int>(n, max_dets_);
+                    static_assert(sizeof(zly_det) == sizeof(Detection), "zly_det must be layout-identical to Detection");
+                    d.state.detections.resize((size_t)cnt);
+                    if (cnt) std::memcpy(d.state.detections.data(), dets.data(), (size_t)cnt * sizeof(Detection));
+                } else {
+                    inference_errors_++;
+                }
+                release(std::move(p.engine));                    // an engine replaced by a reload goes with its last request -- on the reaper thread
             }
-            retire(std::move(p.engine));                         // an engine replaced by a reload goes with its last request -- on the reaper thread
+            group.emplace_back(p.seq, std::move(d));
+            local.pop_front();
         }
         // hand over in submission order
-        std::vector<Done> ready;
+        ready.clear();
         InferenceCallback cb;
         {
             std::lock_guard<std::mutex> lk(queue_mutex_);
-            finished_.emplace(p.seq, std::move(d));
-            while (!finished_.empty() && finished_.begin()->first == next_emit_) {
-                ready.push_back(std::move(finished_.begin()->second));
-                finished_.erase(finished_.begin());
+            for (auto& g : group) {
+                while (g.first - next_emit_ >= ring_.size()) {   // more sequence numbers outstanding than the ring holds: double it (re-placing what it holds)
+                    std::vector<Done> bigger(ring_.size() * 2);
+                    std::vector<uint8_t> full(ring_.size() * 2, 0);
+                    for (uint64_t q = next_emit_; q < next_emit_ + ring_.size(); ++q)
+                        if (ring_full_[q & (ring_.size() - 1)]) { bigger[q & (bigger.size() - 1)] = std::move(ring_[q & (ring_.size() - 1)]); full[q & (bigger.size() - 1)] = 1; }
+                    ring_.swap(bigger); ring_full_.swap(full);
+                }
+                const size_t at = (size_t)(g.first & (ring_.size() - 1));
+                ring_[at] = std::move(g.second); ring_full_[at] = 1; ++finished_count_;
+            }
+            while (ring_full_[next_emit_ & (ring_.size() - 1)]) {
+                const size_t at = (size_t)(next_emit_ & (ring_.size() - 1));
+                ready.push_back(std::move(ring_[at]));
+                ring_full_[at] = 0; --finished_count_;
                 ++next_emit_;
             }
             cb = callback_;
         }
-        for (Done& r : ready) {
-            if (!r.ok) continue;                                 // not invoked on error results (onnx_engine.cpp:380-388)
-            inference_count_++;
-            {
-                std::lock_guard<std::mutex> lk(stats_mutex_);
-                const double lat = (double)(wallMs() - r.enqueue_ms);
+        if (ready.empty()) continue;
+        {
+            std::lock_guard<std::mutex> lk(stats_mutex_);
+            const uint64_t now = wallMs();
+            for (const Done& r : ready) {
+                if (!r.ok) continue;
+                const double lat = (double)(now - r.enqueue_ms);
                 latency_window_ms_.push_back(lat);
                 if (latency_window_ms_.size() > 100) latency_window_ms_.pop_front();
                 total_latency_ms_ += lat;
             }
+        }
+        for (Done& r : ready) {
+            if (!r.ok) continue;                                 // not invoked on error results (onnx_engine.cpp:380-388)
+            inference_count_++;
             if (cb) cb(r.client_id, r.state);
         }
     }
@@ -353,7 +447,7 @@ std::unordered_map<std::string, std::string> HipInferenceEngine::getStatus() con
 {
     std::unordered_map<std::string, std::string> s;
     s["name"] = getName();
-    s["simulation_mode"] = "false";
+    s["simulation_mode"] = simulate_ ? "true" : "false";
     s["running"] = running_ ? "true" : "false";
     s["model_path"] = config_.model_path;
     s["model_version"] = std::to_string(model_version_.load());

@@ -23,8 +23,10 @@
 //     caller's thread (zly_submit); the engine batches whatever is pending -- no batching window, so no added latency --
 //     and overlaps upload, compute and download of consecutive batches (the reference's "dynamic batching" is a TODO
 //     that runs frames one by one, :348-365).  One completion thread hands results to the callback (zly_wait);
-//   * no simulation mode: a missing/bad model file is an error from initialize(), not random boxes
-//     (:70-75,105-110);
+//   * no SILENT simulation mode: a missing/bad model file is an error from initialize(), not random boxes (:70-75,105-110).
+//     The reference's fake backend exists only as an explicit opt-in, ZLY_SIMULATE=1 ("keep only as an explicit --simulate
+//     fallback"): initialize() then creates no engine and every frame gets generateRandomDetections' 0-5 random boxes (:1133-1177) through
+//     the same ordered callback path; getStatus() says simulation_mode = true.  Nothing falls back to it on its own;
 //   * one engine per GPU (ZLY_NUM_DEVICES, default 1; requests go round robin) instead of CPU worker threads.
 #pragma once
 
@@ -65,6 +67,7 @@ private:
         std::shared_ptr<EngineHandle> engine;
         uint64_t ticket = 0;
         bool failed = false;                               // refused by zly_submit (wrong byte count): no callback, keeps the sequence dense
+        bool simulated = false;                            // ZLY_SIMULATE=1: no engine, no ticket; the completion thread draws the reference's random boxes
         uint32_t client_id = 0, frame_id = 0;
         uint64_t timestamp = 0, enqueue_ms = 0;
     };
@@ -73,13 +76,20 @@ private:
     void monitorLoop();
     void reaperLoop();
     void retire(std::shared_ptr<EngineHandle>&& h);         // drop a reference on the reaper thread (the last one destroys the engine there)
+    void release(std::shared_ptr<EngineHandle>&& h);        // a request is done with its engine: plain drop while the engine serves, retire() once a reload replaced it
+    std::vector<Detection> generateRandomDetections();      // onnx_engine.cpp:1133-1177 (ZLY_SIMULATE=1 only)
     std::shared_ptr<EngineHandle> createEngineOn(int device, int32_t* rc, std::string* msg) const;
 
     ServerConfig config_;
     int max_batch_ = 64;
     int max_dets_ = 256;
     mutable std::mutex engines_mutex_;                     // guards the vector (held for pointer copies only, never across a device call)
-    std::vector<std::shared_ptr<EngineHandle>> engines_;   // one per GPU
+    std::vector<std::shared_ptr<EngineHandle>> engines_;   // one per GPU and engine instance
+    // what submitInference reads: an immutable snapshot of engines_, swapped as a whole by initialize / reloadModel / shutdown (std::atomic_load /
+    // atomic_store on the shared_ptr) -- twelve submitting threads used to take engines_mutex_ for every frame
+    std::shared_ptr<const std::vector<std::shared_ptr<EngineHandle>>> engines_snapshot_;
+    bool simulate_ = false;                                // ZLY_SIMULATE=1 (explicit opt-in, see above)
+    uint32_t sim_rng_state_[4] = {0, 0, 0, 0};             // completion thread only
     int first_device_ = 0;
     int engines_per_gpu_ = 1;
     std::thread monitor_, completer_, reaper_;
@@ -102,7 +112,11 @@ private:
     // THIS order (never in sequence order: the owner of the next sequence number may be blocked in zly_submit by ring
     // back-pressure that only consuming later tickets releases), and re-orders the results by sequence number for the callback.
     std::deque<Pending> pending_;
-    std::map<uint64_t, Done> finished_;
+    // results waiting for an earlier sequence number: a ring indexed by seq & (size - 1), grown when the span of outstanding sequence numbers exceeds it
+    // (round 3: a std::map insert + erase per frame).  Touched by the completion thread under queue_mutex_ once per GROUP of completed frames.
+    std::vector<Done> ring_;
+    std::vector<uint8_t> ring_full_;
+    size_t finished_count_ = 0;
     std::atomic<uint64_t> next_seq_{0};
     uint64_t next_emit_ = 0;
     InferenceCallback callback_;

@@ -18,7 +18,10 @@ class FrameServer {
   public:
     using SendFn = std::function<void(uint32_t client_id, const std::vector<uint8_t>& packet)>;
 
-    FrameServer(IInferenceEngine& engine, Cs16DetectionStep& adapter, SendFn send) : engine_(engine), adapter_(adapter), send_(std::move(send))
+    // max_frame_bytes: the largest chunked frame the server will reassemble (FrameAssembler allocates a frame's buffer when its first piece arrives);
+    // pass a few times model_w * model_h * 3.  The default admits a 1920 x 1080 BGR frame.
+    FrameServer(IInferenceEngine& engine, Cs16DetectionStep& adapter, SendFn send, size_t max_frame_bytes = (size_t)8 << 20)
+        : engine_(engine), adapter_(adapter), send_(std::move(send)), assembler_(4, max_frame_bytes)
     {
         // NetworkServer's constructor wires the engine callback to onInferenceResult (network_server.cpp:21-22)
         engine_.setCallback([this](uint32_t client_id, const GameState& state) { onInferenceResult(client_id, state); });
@@ -27,6 +30,20 @@ class FrameServer {
     // one datagram from `client_id` (the reference resolves the id from the sender address, :88-110): a whole frame (FrameDataPacket,
     // the reference's format: frames up to 65518 bytes) or one piece of a chunked raw frame (FrameChunkPacket, zly_wire.hpp)
     Result<void> onPacket(uint32_t client_id, const uint8_t* data, size_t size)
+    {
+        // nothing a datagram contains may take the server down: an allocation failure (or any other exception below) becomes an error result
+        try { return onPacketImpl(client_id, data, size); }
+        catch (const std::bad_alloc&) { ++bad_packets_; return Result<void>::error(ErrorCode::SYSTEM_ERROR, "out of memory while handling a packet"); }
+        catch (const std::exception& ex) { ++bad_packets_; return Result<void>::error(ErrorCode::SYSTEM_ERROR, std::string("exception while handling a packet: ") + ex.what()); }
+    }
+
+    uint64_t reassembledFrames() const { return reassembled_frames_; }
+    uint64_t droppedIncompleteFrames() const { std::lock_guard<std::mutex> lk(assembler_mutex_); return assembler_.dropped(); }
+    uint64_t badPackets() const { return bad_packets_; }
+    uint64_t sentPackets() const { return sent_packets_; }
+
+  private:
+    Result<void> onPacketImpl(uint32_t client_id, const uint8_t* data, size_t size)
     {
         if (size > 5 && data[5] == wire::kTypeFrameChunk) {
             auto chunk = wire::parseFrameChunk(data, size);
@@ -51,12 +68,6 @@ class FrameServer {
         return engine_.submitInference(req.value());
     }
 
-    uint64_t reassembledFrames() const { return reassembled_frames_; }
-    uint64_t droppedIncompleteFrames() const { std::lock_guard<std::mutex> lk(assembler_mutex_); return assembler_.dropped(); }
-    uint64_t badPackets() const { return bad_packets_; }
-    uint64_t sentPackets() const { return sent_packets_; }
-
-  private:
     void onInferenceResult(uint32_t client_id, const GameState& state)
     {
         auto processed = adapter_.processDetections(client_id, state, Cs16DetectionStep::kGameCs16);

@@ -209,6 +209,7 @@ struct FrameChunk {
     uint32_t offset = 0;
     const uint8_t* payload = nullptr;          // points into the parsed packet
     size_t payload_size = 0;
+    uint32_t piece = 0;                        // bytes per piece of this frame's tiling (derived and checked by parseFrameChunk)
 };
 
 // a frame -> ceil(bytes / max_payload) packets, sequence numbers sequence0, sequence0 + 1, ...
@@ -258,9 +259,21 @@ inline Result<FrameChunk> parseFrameChunk(const uint8_t* data, size_t size, Head
     if (c.width == 0 || c.height == 0)
         return R::error(ErrorCode::INVALID_PACKET, "Invalid frame dimensions: " + std::to_string(c.width) + "x" + std::to_string(c.height));
     const size_t total = (size_t)c.width * c.height * 3;
-    if (c.count == 0 || c.index >= c.count || c.payload_size == 0 || (size_t)c.offset + c.payload_size > total)
+    auto bad = [&]() {
         return R::error(ErrorCode::INVALID_PACKET, "Invalid frame chunk: index " + std::to_string(c.index) + " of " + std::to_string(c.count) + ", bytes [" +
                                                            std::to_string(c.offset) + ", " + std::to_string((size_t)c.offset + c.payload_size) + ") of " + std::to_string(total));
+    };
+    if (c.count == 0 || c.index >= c.count || c.payload_size == 0 || (size_t)c.offset + c.payload_size > total) return bad();
+    // The pieces of a frame tile it UNIFORMLY (serializeFrameChunks: piece i = bytes [i * P, min((i + 1) * P, total))), and every piece says enough to
+    // check that on its own: P = offset / index (piece 0: its payload size; a single piece: the frame).  A piece that does not fit the tiling is refused
+    // here, so pieces that pass cannot overlap or leave holes, whatever order they arrive in (the assembler used to accept overlapping
+    // pieces whose sizes happened to add up).
+    size_t P = 0;
+    if (c.count == 1) P = total;
+    else if (c.index == 0) P = c.payload_size;
+    else { if (c.offset % c.index) return bad(); P = c.offset / c.index; }
+    if (P == 0 || P > kMaxChunkPayload || (total + P - 1) / P != c.count || (size_t)c.index * P != c.offset || c.payload_size != std::min(P, total - c.offset)) return bad();
+    c.piece = (uint32_t)P;
     return R::ok(c);
 }
 
@@ -269,12 +282,23 @@ inline Result<FrameChunk> parseFrameChunk(const uint8_t* data, size_t size, Head
 // a frame that lost one never completes -- the oldest incomplete frame makes room (counted in dropped()).
 class FrameAssembler {
   public:
-    explicit FrameAssembler(size_t max_pending = 4) : max_pending_(max_pending ? max_pending : 1) {}
+    // max_frame_bytes bounds what ONE datagram can make the server allocate: a piece's header claims the frame's size (w, h up to 65535: 12.9 GB),
+    // and the buffer is allocated when the first piece arrives.  Default 8 MiB (a 1920 x 1080 BGR frame is 6.2 MB); FrameServer passes a few times
+    // the model's frame size.  With max_pending frames per client that is the most a client can hold.
+    explicit FrameAssembler(size_t max_pending = 4, size_t max_frame_bytes = (size_t)8 << 20)
+        : max_pending_(max_pending ? max_pending : 1), max_frame_bytes_(max_frame_bytes) {}
 
     // -> true when this piece completed its frame (*out then holds it), false when more pieces are needed
     Result<bool> add(uint32_t client_id, const FrameChunk& c, FrameData* out)
     {
         using R = Result<bool>;
+        const size_t total = (size_t)c.width * c.height * 3;
+        if (total > max_frame_bytes_)
+            return R::error(ErrorCode::PACKET_TOO_LARGE, "chunked frame of " + std::to_string(total) + " bytes exceeds the " + std::to_string(max_frame_bytes_) + "-byte limit");
+        // parseFrameChunk has checked the piece against the uniform tiling its own fields imply; a hand-built FrameChunk gets the same check here
+        if (c.piece == 0 || c.count == 0 || c.index >= c.count || (total + c.piece - 1) / c.piece != c.count || (size_t)c.index * c.piece != c.offset ||
+            c.payload_size != std::min((size_t)c.piece, total - std::min(total, (size_t)c.offset)) || c.payload_size == 0)
+            return R::error(ErrorCode::INVALID_PACKET, "frame chunk does not fit the frame's tiling");
         std::deque<Partial>& q = pending_[client_id];
         Partial* p = nullptr;
         for (Partial& x : q) if (x.f.frame_id == c.frame_id) { p = &x; break; }
@@ -283,21 +307,16 @@ class FrameAssembler {
             q.emplace_back();
             p = &q.back();
             p->f.frame_id = c.frame_id; p->f.timestamp = c.timestamp; p->f.width = c.width; p->f.height = c.height; p->f.keyframe = c.keyframe;
-            p->f.data.assign((size_t)c.width * c.height * 3, 0);
+            p->piece = c.piece;
+            p->f.data.assign(total, 0);
             p->have.assign(c.count, false);
-        } else if (p->f.width != c.width || p->f.height != c.height || p->have.size() != c.count || p->f.timestamp != c.timestamp) {
+        } else if (p->f.width != c.width || p->f.height != c.height || p->have.size() != c.count || p->f.timestamp != c.timestamp || p->piece != c.piece) {
             return R::error(ErrorCode::INVALID_PACKET, "frame chunk contradicts the earlier pieces of frame " + std::to_string(c.frame_id));
         }
         if (p->have[c.index]) return R::ok(false);                       // duplicate datagram
         std::memcpy(p->f.data.data() + c.offset, c.payload, c.payload_size);
         p->have[c.index] = true;
-        p->bytes += c.payload_size;
-        if (++p->got < p->have.size()) return R::ok(false);
-        if (p->bytes != p->f.data.size()) {                              // every index seen, yet the pieces do not tile the frame
-            const uint32_t id = c.frame_id;
-            erase(q, id);
-            return R::error(ErrorCode::INVALID_PACKET, "frame chunks of frame " + std::to_string(id) + " do not add up to width*height*3 bytes");
-        }
+        if (++p->got < p->have.size()) return R::ok(false);              // every piece sits at index * piece and has the tiling's size: all indices seen = the frame is whole
         *out = std::move(p->f);
         erase(q, c.frame_id);
         return R::ok(true);
@@ -306,12 +325,12 @@ class FrameAssembler {
     size_t pending(uint32_t client_id) const { auto it = pending_.find(client_id); return it == pending_.end() ? 0 : it->second.size(); }
 
   private:
-    struct Partial { FrameData f; std::vector<bool> have; size_t got = 0, bytes = 0; };
+    struct Partial { FrameData f; std::vector<bool> have; size_t got = 0; uint32_t piece = 0; };
     static void erase(std::deque<Partial>& q, uint32_t frame_id)
     {
         for (auto it = q.begin(); it != q.end(); ++it) if (it->f.frame_id == frame_id) { q.erase(it); return; }
     }
-    size_t max_pending_;
+    size_t max_pending_, max_frame_bytes_;
     std::map<uint32_t, std::deque<Partial>> pending_;
     uint64_t dropped_ = 0;
 };

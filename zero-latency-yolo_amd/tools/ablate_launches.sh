@@ -3,6 +3,9 @@
 # launch left out (ZLY_ABLATE_SKIP, results garbage): step time saved = the launch's marginal cost with the other chains overlapping it.
 # Output: gpurun_out/ablate.txt  (op | isolated us from profiles/r03_per_launch.json | ms/step without it | saved us)
 out=gpurun_out/ablate; mkdir -p $out
+# ZLY_ABLATE_SKIP exists in the diagnostic library only (make diaglib); the shipped libzly.so ignores it
+export ZLY_LIB=$(pwd)/zero-latency-yolo_amd/_build/libzly_diag.so
+[ -f "$ZLY_LIB" ] || { echo "build it first: make diaglib"; exit 1; }
 export ZLY_BENCH_NO_H2H=1
 run() { python3 bench.py --batch 64 --steps 20 --warmup 5 --blocks 12 --no-extras --no-cpu-baseline "$@" 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.readline()); print(d['ms_per_step'])"; }
 base=$(run)

@@ -20,11 +20,16 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) int i32x8;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
-enum { BF16 = 0, FP8 = 1, FP8S = 2 };
+enum { BF16 = 0, FP8 = 1, FP8S = 2, BF16K16 = 3 };          // BF16K16: v_mfma_f32_16x16x16_bf16 (the 4-bf16-per-lane form the 16-channel layers use)
 
 template <int KIND> __device__ __forceinline__ f32x4 mma(const u32x4& a0, const u32x4& a1, const u32x4& b0, const u32x4& b1, f32x4 c)
 {
     if constexpr (KIND == BF16) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a0), __builtin_bit_cast(bf16x8, b0), c, 0, 0, 0);
+    else if constexpr (KIND == BF16K16) {
+        typedef __attribute__((ext_vector_type(4))) short s16x4;
+        const s16x4 sa = {(short)a0[0], (short)(a0[0] >> 16), (short)a0[1], (short)(a0[1] >> 16)}, sb = {(short)b0[0], (short)(b0[0] >> 16), (short)b0[1], (short)(b0[1] >> 16)};
+        return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(sa, sb, c, 0, 0, 0);
+    }
     else if constexpr (KIND == FP8) {
         // K = 32 fp8 values per MFMA: 8 bytes per lane per operand
         const long la = (long)a0[0] | ((long)a0[1] << 32), lb = (long)b0[0] | ((long)b0[1] << 32);
@@ -118,6 +123,10 @@ int main()
         ms[0] = time_ms([&] { hipLaunchKernelGGL(issue_kernel<BF16>, dim3(grid), dim3(256), 0, 0, d, iters); });
         ms[1] = time_ms([&] { hipLaunchKernelGGL(issue_kernel<FP8>, dim3(grid), dim3(256), 0, 0, d, iters); });
         ms[2] = time_ms([&] { hipLaunchKernelGGL(issue_kernel<FP8S>, dim3(grid), dim3(256), 0, 0, d, iters); });
+        {
+            const float m16 = time_ms([&] { hipLaunchKernelGGL(issue_kernel<BF16K16>, dim3(grid), dim3(256), 0, 0, d, iters); });
+            printf("   %d wave(s)/SIMD  bf16  16x16x16            %8.1f TFLOP/s  (%.2f x the time of a 16x16x32 per instruction)\n", wps, 2.0 * grid * 4 * (double)iters * 27 * 16 * 16 * 16 / (m16 * 1e-3) / 1e12, m16 / ms[0]);
+        }
         for (int k = 0; k < 3; ++k) {
             const double flops = 2.0 * grid * 4 * (double)iters * 27 * 16 * 16 * (k == 2 ? 128 : 32);
             const double tf = flops / (ms[k] * 1e-3) / 1e12;
