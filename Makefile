@@ -12,9 +12,9 @@ HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -I$(CSRC) -Wal
 CXX      ?= g++
 PY       ?= python3
 
-KERNELS  := $(CSRC)/kernels_conv.hip $(CSRC)/kernels_pair.hip $(CSRC)/kernels_misc.hip $(CSRC)/kernels_head.hip $(CSRC)/kernels_stem.hip $(CSRC)/kernels_post.hip $(CSRC)/kernels_c2f64.hip
+KERNELS  := $(CSRC)/kernels_conv.hip $(CSRC)/kernels_pair.hip $(CSRC)/kernels_misc.hip $(CSRC)/kernels_head.hip $(CSRC)/kernels_stem.hip $(CSRC)/kernels_post.hip $(CSRC)/kernels_c2f64.hip $(CSRC)/kernels_sppf.hip
 ENGINE   := $(CSRC)/engine.cpp $(CSRC)/weights.cpp
-OBJS     := $(OUT)/kernels_conv.o $(OUT)/kernels_pair.o $(OUT)/kernels_misc.o $(OUT)/kernels_head.o $(OUT)/kernels_stem.o $(OUT)/kernels_post.o $(OUT)/kernels_c2f64.o $(OUT)/engine.o $(OUT)/weights.o
+OBJS     := $(OUT)/kernels_conv.o $(OUT)/kernels_pair.o $(OUT)/kernels_misc.o $(OUT)/kernels_head.o $(OUT)/kernels_stem.o $(OUT)/kernels_post.o $(OUT)/kernels_c2f64.o $(OUT)/kernels_sppf.o $(OUT)/engine.o $(OUT)/weights.o
 
 all: $(OUT)/libzly.so $(OUT)/libzly_gather.so $(OUT)/test_gather oracle weights host
 

@@ -173,6 +173,10 @@ int32_t zly_detect_batch(zly_engine* e, int32_t n, const uint8_t* const* bgr, co
  * batch returns its error code from zly_wait for each of its tickets.  Wrong byte counts fail in zly_submit with
  * ZLY_ERR_INVALID_INPUT (onnx_engine.cpp:659-665) and produce no ticket. */
 int32_t zly_submit(zly_engine* e, const uint8_t* bgr, size_t nbytes, int32_t w, int32_t h, uint64_t* ticket);
+/* zly_submit that never blocks: ZLY_PENDING (no ticket, nothing copied) when every ring slot of this engine is busy.  A host that feeds
+ * several engines (the plugin: one per GPU / engine instance) offers a frame to the next engine in turn and, only if that one is
+ * back-pressured, to the others -- with the blocking call alone, submitting threads that all wait on one engine's ring starve the rest. */
+int32_t zly_submit_try(zly_engine* e, const uint8_t* bgr, size_t nbytes, int32_t w, int32_t h, uint64_t* ticket);
 int32_t zly_poll(zly_engine* e, uint64_t ticket);
 int32_t zly_wait(zly_engine* e, uint64_t ticket, zly_det* out, int32_t cap, int32_t* n_out);
 

@@ -1,7 +1,7 @@
 // test_plugin_stub.cpp -- the plugin's HOST logic with several engines per process, without a GPU: round-robin over the engine handles,
 // re-ordering of results that finish out of order, error frames that keep the sequence dense, hot reload with requests in flight, and WHERE
 // replaced engines are destroyed.  TEST INFRASTRUCTURE: host/hip_inference_engine.cpp is compiled into this binary together with a
-// link-time stub of the C-ABI entry points it calls (zly_create / zly_destroy / zly_submit / zly_poll / zly_wait / zly_get_stats / zly_weights_fp8 /
+// link-time stub of the C-ABI entry points it calls (zly_create / zly_destroy / zly_submit / zly_submit_try / zly_poll / zly_wait / zly_get_stats / zly_weights_fp8 /
 // zly_default_config / zly_last_error).  The stub is not a CPU fallback of the product: libzly.so has none, and this file is never linked
 // into it.  A fake engine "detects" one box per frame whose fields encode (engine ordinal, device, first pixel of the frame), and
 // finishes its tickets after a per-engine delay, so that engines complete out of order.
@@ -60,6 +60,7 @@ int32_t zly_submit(zly_engine* e, const uint8_t* bgr, size_t nbytes, int32_t w, 
     e->pending[*ticket] = std::make_pair(bgr[0], ready);
     return ZLY_OK;
 }
+int32_t zly_submit_try(zly_engine* e, const uint8_t* bgr, size_t nbytes, int32_t w, int32_t h, uint64_t* ticket) { return zly_submit(e, bgr, nbytes, w, h, ticket); }   // the stub's ring is never full
 int32_t zly_poll(zly_engine* e, uint64_t ticket)
 {
     std::lock_guard<std::mutex> lk(e->mu);

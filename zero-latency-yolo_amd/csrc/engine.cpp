@@ -170,12 +170,13 @@ struct zly_engine {
     hipEvent_t ev_call[2] = {nullptr, nullptr};
     uint64_t call_seq = 0;
     int det_stem[3] = {-1, -1, -1}, det_a[3] = {-1, -1, -1}, det_b[3] = {-1, -1, -1};   // op indices of the Detect convs (stem, box .1, class .1) per level
+    int sppf_cv1 = -1, sppf_pool = -1, sppf_cv2 = -1;     // op indices of the SPPF block (model.9): one launch where kernels_sppf.hip covers the shape
     int cu_part_n = 1;                // ZLY_CU_PART: number of CU partitions (1 = whole chip)
     uint32_t cu_mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     std::atomic<Ingest*> ingest{nullptr};   // created by the first zly_submit (under mu), read lock-free afterwards
 
     // tuning / test switches of the environment, read ONCE at zly_create (they used to be read per launch)
-    struct Switches { bool no_c2f = false, no_det_merge = false, no_tail_split = false, no_lanes = false, nms_general = false; int stem1_nw = 0, stem1_var = 1; std::string ablate; } sw;
+    struct Switches { bool no_c2f = false, no_det_merge = false, no_tail_split = false, no_lanes = false, nms_general = false, no_sppf = false; int stem1_nw = 0, stem1_var = 1; std::string ablate; } sw;
 
     std::mutex mu;                    // serialises every call that touches engine / device state
     mutable std::mutex stats_mu;      // guards `stats` only, never held across a device call: zly_get_stats cannot wait on a batch
@@ -574,6 +575,9 @@ static int build_plan_host(zly_engine* e, PlanState* ps, std::string* err)
         for (size_t i = 0; i < e->ops.size(); ++i) by_name[e->ops[i].name] = (int)i;
         for (Op& op : e->ops)
             if (!op.c2f_leader_name.empty()) op.c2f_leader = by_name[op.c2f_leader_name];
+        if (by_name.count("model.9.cv1") && by_name.count("model.9.pool") && by_name.count("model.9.cv2")) {
+            e->sppf_cv1 = by_name["model.9.cv1"]; e->sppf_pool = by_name["model.9.pool"]; e->sppf_cv2 = by_name["model.9.cv2"];
+        }
         // Detect convs, for the merged launches of the latency path: all three levels must suit the shared kernel shape
         bool det_ok = e->dtype == ZLY_DTYPE_BF16;
         for (int l = 0; l < 3 && det_ok; ++l) {
@@ -768,12 +772,24 @@ static int detect_merge_role(const zly_engine* e, int i)
     return 0;
 }
 
+// SPPF as one launch (kernels_sppf.hip) at the block's first op; the pool and cv2 ops then launch nothing
+static bool sppf_active(const zly_engine* e)
+{
+    if (e->dtype != ZLY_DTYPE_BF16 || e->sppf_cv1 < 0 || (e->cfg.flags & ZLY_FLAG_NO_FUSION) || e->sw.no_sppf) return false;
+    const Op& a = e->ops[(size_t)e->sppf_cv1];
+    const Op& b = e->ops[(size_t)e->sppf_cv2];
+    const Buffer& ob = e->bufs[(size_t)b.out.buf];
+    if (!a.act || !b.act || a.res.buf >= 0 || b.res.buf >= 0 || a.in2.buf >= 0 || b.in.C != 4 * a.cout || a.cout_pad != a.cout || b.cout_pad != b.cout) return false;
+    return sppf_fused_ok(a.in.C, a.cout, b.cout, ob.H, ob.W);
+}
+
 // ops that launch nothing at this batch size (second conv of a fused pair; per-level tail ops when one launch covers all)
 static bool op_is_noop(zly_engine* e, const Op& op, int n)
 {
     if (op.kind == OP_PREPROCESS) return e->stem_fused;                          // detect paths: inside the stem kernel
     if (op.kind == OP_CONV && e->stem1 && op.name == "model.1") return true;     // detect paths: computed by stem_model1_kernel (booked on model.0)
     if (op.kind == OP_CONV && c2f_covered(e, op, n)) return true;
+    if ((op.kind == OP_SPPF || (op.kind == OP_CONV && (int)(&op - e->ops.data()) == e->sppf_cv2)) && sppf_active(e)) return true;
     if (op.kind == OP_CONV && detect_merge_active(e, n) && detect_merge_role(e, (int)(&op - e->ops.data())) == 1) return true;
     if (op.kind == OP_CONV && op.pair == 2) return pair_active(e, op, n) != nullptr;
     if (op.kind == OP_HEAD && op.level != 2) return !lanes_active(e, n) || e->sw.no_tail_split;
@@ -789,6 +805,7 @@ static int op_covered_by(zly_engine* e, int i, int n)
     if (op.kind == OP_CONV) {
         if (i == 2 && e->stem1) return 1;
         if (c2f_covered(e, op, n)) return op.c2f_leader;
+        if (i == e->sppf_cv2 && sppf_active(e)) return e->sppf_cv1;
         if (detect_merge_active(e, n) && detect_merge_role(e, i) == 1) {
             for (int l = 0; l < 3; ++l) if (i == e->det_stem[l]) return e->det_stem[2];
             return e->det_a[2];
@@ -796,6 +813,7 @@ static int op_covered_by(zly_engine* e, int i, int n)
         if (op.pair == 2 && pair_active(e, op, n)) return i - 1;
         return i;
     }
+    if (op.kind == OP_SPPF && sppf_active(e)) return e->sppf_cv1;
     if (op.kind == OP_HEAD && op_is_noop(e, op, n)) {
         for (size_t k = 0; k < e->ops.size(); ++k) if (e->ops[k].kind == OP_HEAD && e->ops[k].level == 2) return (int)k;
     }
@@ -844,6 +862,25 @@ static hipError_t run_op(zly_engine* e, const Op& op, int n, const uint8_t* d_sr
     case OP_CONV: {
         const Buffer& ib = e->bufs[(size_t)op.in.buf];
         if (c2f_covered(e, op, n)) return hipSuccess;               // computed by the fused C2f kernel launched at its leader
+        if (sppf_active(e)) {
+            const int oi = (int)(&op - e->ops.data());
+            if (oi == e->sppf_cv2) return hipSuccess;               // computed by the fused SPPF kernel launched at model.9.cv1
+            if (oi == e->sppf_cv1) {
+                const Op& o2 = e->ops[(size_t)e->sppf_cv2];
+                const Buffer& cb = e->bufs[(size_t)op.out.buf];     // the block's concat buffer [y | p1 | p2 | p3]
+                const Buffer& ob2 = e->bufs[(size_t)o2.out.buf];
+                const char* wb = (const char*)e->d_weights;
+                SppfArgs sa{};
+                sa.x = ib.ptr; sa.x_cs = ib.C; sa.x_co = op.in.co; sa.Cin = op.in.C;
+                sa.w1 = wb + op.w_off; sa.b1 = (const float*)(wb + op.b_off);
+                sa.w2 = wb + o2.w_off; sa.b2 = (const float*)(wb + o2.b_off);
+                sa.out = ob2.ptr; sa.out_cs = ob2.C; sa.out_co = o2.out.co; sa.Cout = o2.cout;
+                sa.cat = cb.ptr; sa.cat_cs = cb.C;
+                sa.H = cb.H; sa.W = cb.W; sa.n = n; sa.c = op.cout; sa.split = 0;
+                sa.dump = (e->cfg.flags & ZLY_FLAG_DUMP_LOGITS) ? 1 : 0;
+                return launch_sppf_fused(sa, s);
+            }
+        }
         if (detect_merge_active(e, n)) {
             const int role = detect_merge_role(e, (int)(&op - e->ops.data()));
             if (role == 1) return hipSuccess;
@@ -899,6 +936,7 @@ static hipError_t run_op(zly_engine* e, const Op& op, int n, const uint8_t* d_sr
         return launch_conv(e->dtype, a, conv_launch_of(e, op, n), s);
     }
     case OP_SPPF: {
+        if (sppf_active(e)) return hipSuccess;                       // inside the fused SPPF kernel
         const Buffer& b = e->bufs[(size_t)op.in.buf];
         return launch_sppf_pool(e->dtype, b.ptr, b.C, op.c, n, b.H, b.W, s);
     }
@@ -1465,7 +1503,7 @@ static void ingest_free(zly_engine* e, Ingest* g)
     delete g;                                          // the copy streams are shared by the process and stay
 }
 
-static int ingest_submit(zly_engine* e, const uint8_t* bgr, size_t nbytes, int32_t w, int32_t h, uint64_t* ticket)
+static int ingest_submit(zly_engine* e, const uint8_t* bgr, size_t nbytes, int32_t w, int32_t h, uint64_t* ticket, bool nonblock = false)
 {
     if (!bgr || w <= 0 || h <= 0 || nbytes != (size_t)w * (size_t)h * 3u) {
         with_stats(e, [](zly_stats& st) { st.inference_errors++; });
@@ -1487,7 +1525,11 @@ static int ingest_submit(zly_engine* e, const uint8_t* bgr, size_t nbytes, int32
         std::unique_lock<std::mutex> lk(g->mu);
         while (true) {
             if (g->stop) return fail(ZLY_ERR_NOT_INITIALIZED, "Engine not running");
-            if (g->open < 0 && !ingest_try_open(e, g)) { g->cv_free.wait(lk); continue; }     // every ring slot is busy: back-pressure
+            if (g->open < 0 && !ingest_try_open(e, g)) {                                       // every ring slot is busy: back-pressure
+                if (nonblock) return ZLY_PENDING;                                                // zly_submit_try: the caller offers the frame elsewhere
+                g->cv_free.wait(lk);
+                continue;
+            }
             IngestSlot& o = g->slots[(size_t)g->open];
             if (o.n_reserved >= e->cfg.max_batch || o.bytes_used + padded > g->slot_bytes) {   // full: the dispatcher takes it from here
                 ingest_close_open(g);
@@ -1653,6 +1695,7 @@ int32_t zly_create(const zly_config* cfg, zly_engine** out)
     e->sw.no_det_merge = getenv("ZLY_NO_DET_MERGE") != nullptr;
     e->sw.no_tail_split = getenv("ZLY_NO_TAIL_SPLIT") != nullptr;
     e->sw.no_lanes = getenv("ZLY_NO_LANES") != nullptr || getenv("ZLY_CU_PART") != nullptr;
+    e->sw.no_sppf = getenv("ZLY_NO_SPPF_FUSED") != nullptr;                      // tuning / tests: SPPF as three launches
     e->sw.nms_general = getenv("ZLY_NMS_GENERAL") != nullptr;                     // tests / A-B: every frame on NMS's eight-wave path
     if (const char* v = getenv("ZLY_STEM1_NW")) e->sw.stem1_nw = atoi(v);           // tuning aids: waves per workgroup of the front kernel (12 / 16), ...
     if (const char* v = getenv("ZLY_STEM1_VAR")) e->sw.stem1_var = atoi(v);         // ... and 0 = round 3's staging / tap order (A/B on one box)
@@ -1672,6 +1715,7 @@ int32_t zly_create(const zly_config* cfg, zly_engine** out)
         HIP_TRY(pair_init(), ZLY_ERR_SYSTEM);
         HIP_TRY(stem1_init(), ZLY_ERR_SYSTEM);
         HIP_TRY(c2f_init(), ZLY_ERR_SYSTEM);
+        HIP_TRY(sppf_init(), ZLY_ERR_SYSTEM);
         HIP_TRY(nms_init(), ZLY_ERR_SYSTEM);
         // ZLY_CU_PART="i/n": this engine's streams only use the i-th of n equal slices of the chip's compute units (spatial
         // partitioning: several engines run side by side, the launch-latency-bound small-map layers of one beside the
@@ -1843,6 +1887,13 @@ int32_t zly_submit(zly_engine* e, const uint8_t* bgr, size_t nbytes, int32_t w, 
     if (!e) return fail(ZLY_ERR_NOT_INITIALIZED, "Engine not running");
     if (!ticket) return fail(ZLY_ERR_INVALID_ARGUMENT, "null ticket");
     return ingest_submit(e, bgr, nbytes, w, h, ticket);
+}
+
+int32_t zly_submit_try(zly_engine* e, const uint8_t* bgr, size_t nbytes, int32_t w, int32_t h, uint64_t* ticket)
+{
+    if (!e) return fail(ZLY_ERR_NOT_INITIALIZED, "Engine not running");
+    if (!ticket) return fail(ZLY_ERR_INVALID_ARGUMENT, "null ticket");
+    return ingest_submit(e, bgr, nbytes, w, h, ticket, true);
 }
 
 int32_t zly_poll(zly_engine* e, uint64_t ticket)
@@ -2062,6 +2113,8 @@ int32_t zly_debug_tap(zly_engine* e, const char* name, int32_t idx, float* out, 
                 (op.c2f_vis == 2 || (op.c2f_vis == 1 && !(e->cfg.flags & ZLY_FLAG_DUMP_LOGITS))))
                 return fail(ZLY_ERR_INVALID_ARGUMENT, std::string("tap ") + name + " stays in LDS inside the fused C2f kernel at this batch size; create the engine with " +
                                                           (op.c2f_vis == 1 ? "ZLY_FLAG_DUMP_LOGITS or " : "") + "ZLY_FLAG_NO_FUSION");
+            if (it->second.first == e->sppf_cv1 && sppf_active(e) && !(e->cfg.flags & ZLY_FLAG_DUMP_LOGITS))
+                return fail(ZLY_ERR_INVALID_ARGUMENT, std::string("tap ") + name + " stays in LDS inside the fused SPPF kernel; create the engine with ZLY_FLAG_DUMP_LOGITS or ZLY_FLAG_NO_FUSION");
             if (op.pair == 1 && e->last_n > 0 && pair_active(e, op, e->last_n))
                 return fail(ZLY_ERR_INVALID_ARGUMENT, std::string("tap ") + name + " stays in LDS inside the fused bottleneck kernel at this batch size; create the engine with ZLY_FLAG_NO_FUSION");
             buf = op.out.buf; co = op.out.co + op.tap_co[(size_t)it->second.second]; C = op.tap_c[(size_t)it->second.second];
@@ -2113,13 +2166,18 @@ int32_t zly_op_kernel_name(zly_engine* e, int32_t i, int32_t n, char* out, size_
     std::string k;
     switch (op.kind) {
     case OP_PREPROCESS: k = e->stem_fused ? "(fused into stem_fused_kernel)" : "preprocess_kernel"; break;
-    case OP_SPPF: k = "sppf_pool_kernel"; break;
+    case OP_SPPF: k = sppf_active(e) ? "(fused into the SPPF kernel at model.9.cv1)" : "sppf_pool_kernel"; break;
     case OP_HEAD: k = op_is_noop(e, op, n) ? "(covered by the last tail launch)" : "head_fused_kernel"; break;
     case OP_NMS: k = "nms_kernel"; break;
     case OP_CONV: {
         if (i == 1 && e->stem1) { k = "stem_model1_kernel (preprocess+model.0+model.1)"; break; }
         if (i == 2 && e->stem1) { k = "(fused into the previous launch)"; break; }
         if (i == 1 && e->stem_fused) { k = "stem_fused_kernel"; break; }
+        if (sppf_active(e) && (i == e->sppf_cv1 || i == e->sppf_cv2)) {
+            k = i == e->sppf_cv2 ? std::string("(fused into the SPPF kernel at model.9.cv1)")
+                                 : "sppf_fused_kernel<cv1+3 pools+cv2,SPLIT=" + std::to_string(sppf_split(e->ops[(size_t)e->sppf_cv2].cout, n)) + ">";
+            break;
+        }
         if (detect_merge_active(e, n) && detect_merge_role(e, i)) {
             const int role = detect_merge_role(e, i);
             k = role == 1 ? "(in a merged Detect launch)" : role == 2 ? "conv_igemm_multi_kernel<CT=3> (the 3 Detect stems)" : "conv_igemm_multi_kernel<CT=2> (the 6 Detect branch convs)";

@@ -131,6 +131,22 @@ hipError_t stem1_init();
 hipError_t launch_stem_model1(const Stem1Args& a, int n, hipStream_t s);
 const int* stem1_tap_slot();              // [9]: k slot of tap ky * 3 + kx in Stem1Args::wgt0p (weights.h: repack_conv's tap_slot)
 
+// kernels_sppf.hip -- SPPF (cv1 -> three 5x5 max pools -> cv2 over the concat) as one kernel; bf16, hidden width 128, maps of up to 176 pixels
+struct SppfArgs {
+    const void* x; int x_cs, x_co, Cin;       // cv1 input (NHWC view)
+    const void* w1; const float* b1;          // cv1: tiled [c/16][Cin/32][lane][8], pair-permuted rows
+    const void* w2; const float* b2;          // cv2: tiled [Cout/16][4c/32][lane][8], k in concat order [y | p1 | p2 | p3], pair-permuted rows
+    void* out; int out_cs, out_co, Cout;
+    void* cat; int cat_cs;                    // the block's concat buffer in HBM: written only with dump (debug taps)
+    int H, W, n, c;
+    int split;                                // workgroups per frame (2 / 4), 0 = chosen from n
+    int dump;
+};
+bool       sppf_fused_ok(int cin, int c, int cout, int H, int W);
+int        sppf_split(int cout, int n);
+hipError_t sppf_init();
+hipError_t launch_sppf_fused(const SppfArgs& a, hipStream_t s);
+
 // kernels_head.hip -- fused Detect head (final 1x1 convs + DFL + dist2bbox + sigmoid + decode/threshold)
 struct HeadLevel {
     const void* box_in; const void* cls_in;   // [n][H*W][cs] activations of the two branches' second 3x3 convs

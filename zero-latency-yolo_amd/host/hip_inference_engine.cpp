@@ -285,12 +285,24 @@ Result<void> HipInferenceEngine::submitInference(const InferenceRequest& request
         p.simulated = true;
     } else {
         const auto snap = std::atomic_load(&engines_snapshot_);                           // immutable snapshot: no lock shared by the submitting threads
-        if (snap && !snap->empty()) p.engine = (*snap)[(size_t)(seq % snap->size())];     // one-frame-per-engine round robin
-        if (!p.engine) {
+        if (!snap || snap->empty()) {
             p.failed = true;
         } else {
-            // a request with the wrong byte count fails alone (INVALID_INPUT, onnx_engine.cpp:659-665): counted, no callback
-            const int32_t rc = zly_submit(p.engine->e, request.data.data(), request.data.size(), request.width, request.height, &p.ticket);
+            // One frame per engine, round robin -- offered without blocking first: when the engine whose turn it is has every ring slot
+            // busy, the frame goes to the next one that has room, and only if all are back-pressured does the caller wait (on the engine whose turn
+            // it was).  With the blocking call alone all submitting threads ended up waiting on ONE engine's ring while the other idled (round 4:
+            // plugin 72k -> 77k frames/s against the C ABI's 86-94k with threads pinned to engines).  Results are re-ordered by sequence number.
+            // A request with the wrong byte count fails alone (INVALID_INPUT, onnx_engine.cpp:659-665): counted, no callback.
+            const size_t ne = snap->size(), first = (size_t)(seq % ne);
+            int32_t rc = ZLY_PENDING;
+            for (size_t k = 0; k < ne && rc == ZLY_PENDING; ++k) {
+                p.engine = (*snap)[(first + k) % ne];
+                rc = zly_submit_try(p.engine->e, request.data.data(), request.data.size(), request.width, request.height, &p.ticket);
+            }
+            if (rc == ZLY_PENDING) {
+                p.engine = (*snap)[first];
+                rc = zly_submit(p.engine->e, request.data.data(), request.data.size(), request.width, request.height, &p.ticket);
+            }
             if (rc != ZLY_OK) { p.failed = true; p.engine.reset(); }
         }
         if (p.failed) inference_errors_++;

@@ -35,7 +35,7 @@ FLAG_SINGLE_CHAIN = 16
 # every symbol include/zly.h declares (tests/test_abi.py checks the library exports them all)
 SYMBOLS = [
     "zly_default_config", "zly_create", "zly_destroy", "zly_last_error", "zly_version",
-    "zly_detect", "zly_detect_batch", "zly_submit", "zly_poll", "zly_wait", "zly_detect_device", "zly_slab_bytes", "zly_read_slabs", "zly_sync", "zly_join",
+    "zly_detect", "zly_detect_batch", "zly_submit", "zly_submit_try", "zly_poll", "zly_wait", "zly_detect_device", "zly_slab_bytes", "zly_read_slabs", "zly_sync", "zly_join",
     "zly_preprocess", "zly_forward", "zly_head_tensor", "zly_postprocess", "zly_debug_tap",
     "zly_num_classes", "zly_weights_fp8", "zly_num_anchors", "zly_num_ops", "zly_op_info_at", "zly_launch_info_at", "zly_op_kernel_name", "zly_profile_ops", "zly_get_stats",
 ]
@@ -100,6 +100,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.zly_detect.argtypes = [vp, vp, sz, i32, i32, vp, i32, pi32]; lib.zly_detect.restype = i32
     lib.zly_detect_batch.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(sz), pi32, pi32, vp, i32, pi32]; lib.zly_detect_batch.restype = i32
     lib.zly_submit.argtypes = [vp, vp, sz, i32, i32, C.POINTER(C.c_uint64)]; lib.zly_submit.restype = i32
+    lib.zly_submit_try.argtypes = [vp, vp, sz, i32, i32, C.POINTER(C.c_uint64)]; lib.zly_submit_try.restype = i32
     lib.zly_poll.argtypes = [vp, C.c_uint64]; lib.zly_poll.restype = i32
     lib.zly_wait.argtypes = [vp, C.c_uint64, vp, i32, pi32]; lib.zly_wait.restype = i32
     lib.zly_detect_device.argtypes = [vp, i32, vp, i32, i32, vp, u32, vp]; lib.zly_detect_device.restype = i32
