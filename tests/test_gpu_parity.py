@@ -356,7 +356,7 @@ def test_production_kernels_layerwise_vs_oracle(weights_path, oracle, ref_fp32, 
                                        (416, 416, 3, {"ZLY_WS1_NO_DUAL": "1"}), (352, 288, 5, {"ZLY_WS1": "2", "ZLY_WS1_MIN_PX": "1", "ZLY_WS1_MAX_BYTES": "1"}),
                                        (352, 288, 5, {"ZLY_NO_WS_S2": "1"}), (224, 416, 4, {"ZLY_NO_WS_S2": "1"}), (352, 288, 5, {"ZLY_NO_WS_S2_C32": "1"}),
                                        (352, 288, 5, {"ZLY_WS_MAX_BYTES": "1"}), (416, 416, 3, {"ZLY_STEM1_VAR": "0"}), (352, 288, 5, {"ZLY_STEM1_VAR": "0"}),
-                                       (416, 416, 3, {"ZLY_NO_SPPF_FUSED": "1"}), (224, 416, 4, {"ZLY_NO_SPPF_FUSED": "1"})])
+                                       (416, 416, 3, {"ZLY_SPPF_FUSED": "1"}), (224, 416, 4, {"ZLY_SPPF_FUSED": "1"}), (352, 288, 5, {"ZLY_SPPF_FUSED": "1"})])
 def test_throughput_kernels_on_ragged_maps(weights_path, oracle, monkeypatch, w, h, n, env):
     """conv3x3_lds_kernel, conv1x1_stream_kernel and bottleneck_pair_kernel forced onto small batches of ragged maps (88x72 ..
     11x9, 104x104 .. 13x13, 56x104 .. 7x13: partial tiles on every edge, 13-row maps, last pixel groups that are not full,
@@ -368,7 +368,7 @@ def test_throughput_kernels_on_ragged_maps(weights_path, oracle, monkeypatch, w,
     beyond 32-bit byte offsets; ZLY_NO_WS_S2=1 (ZLY_NO_WS_S2_C32=1): the stride-2 convs with 32 / 64 (32) input channels on the LDS-tiled kernel instead of the weight-stationary one
     (the default runs cover that one: ragged 44x36 -> 22x18 and 28x52 -> 14x26 maps); ZLY_WS_MAX_BYTES=1: the weight-stationary 3x3 kernel's fall-back for tensors
     beyond 32-bit byte offsets; ZLY_STEM1_VAR=0: the front kernel's round-3 staging / tap order (the default, conflict-free one runs in every other case);
-    ZLY_NO_SPPF_FUSED=1: SPPF as cv1 | pool | cv2 launches (every other case runs the fused SPPF kernel; both are checked tap by tap: model.9.cv1, model.9.cv2)."""
+    ZLY_SPPF_FUSED=1: the opt-in fused SPPF kernel (cv1 + three pools + cv2 in one launch; checked tap by tap like the three-launch form: model.9.cv1, model.9.cv2)."""
     import yolov8_ref
     for k, v in dict(ZLY_LDS_MIN_TILES="1", ZLY_STREAM_MIN_GROUPS="1", ZLY_PAIR_MIN_TILES="1", ZLY_WS_MIN_TILES="1", **env).items():
         monkeypatch.setenv(k, v)
@@ -395,9 +395,9 @@ def test_throughput_kernels_on_ragged_maps(weights_path, oracle, monkeypatch, w,
         assert "conv1x1_ws_kernel" not in kn, kn
     if "ZLY_C2F64" in env:
         assert "c2f_kernel<C=64" in kn, kn
-    # SPPF: one launch (kernels_sppf.hip: 13 x 13, 11 x 9 and 7 x 13 maps here, split 4 ways by output channels) unless switched off
-    assert ("sppf_fused_kernel" in kn) == ("ZLY_NO_SPPF_FUSED" not in env), kn
-    assert ("sppf_pool_kernel" in kn) == ("ZLY_NO_SPPF_FUSED" in env), kn
+    # SPPF: cv1 | pool | cv2 launches by default; ZLY_SPPF_FUSED=1: one launch (kernels_sppf.hip: 13 x 13, 7 x 13 and 11 x 9 maps here, split 4 ways by output channels)
+    assert ("sppf_fused_kernel" in kn) == ("ZLY_SPPF_FUSED" in env), kn
+    assert ("sppf_pool_kernel" in kn) == ("ZLY_SPPF_FUSED" not in env), kn
     got = e.forward(x)
     checked = _check_taps(e, ref, range(n), skip_ok=(".m.0.cv1", ".m.1.cv1"))
     assert len(checked) >= 59, checked

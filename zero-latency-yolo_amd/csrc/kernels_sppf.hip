@@ -28,11 +28,19 @@ static constexpr int SPPF_NW = 16;
 static constexpr int SPPF_TP = SPPF_C * 2 + 32;   // TRUE pixel pitch (bytes): fragment reads as in conv1x1_ws_kernel
 static constexpr int SPPF_MAXPX = 176;        // 11 pixel tiles
 
+#ifdef ZLY_SPPF_DIAG
+__device__ unsigned long long* g_sppf_diag = nullptr;            // diagnostic build only (tools/sppf_bench.hip): per-wave cycle sums of the phases
+#define SPPFSTAMP(k) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); dsum[k] += t_ - dT0; dT0 = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define SPPFSTAMP(k) do { } while (0)
+#endif
+
 __device__ __forceinline__ u32x4 sortable(u32x4 v)
 {
-    const s16x8 x = __builtin_bit_cast(s16x8, v);
-    const s16x8 m = (x >> 15) & (short)0x7fff;
-    return __builtin_bit_cast(u32x4, (s16x8)(x ^ m));
+    u32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const unsigned sg = v[i] & 0x80008000u; r[i] = v[i] ^ (sg - (sg >> 15)); }     // per half-word: negative -> flip the low 15 bits (0x8000 - 1 = 0x7fff, no borrow between the halves)
+    return r;
 }
 
 template <int NK1, int NP2>      // NK1: cv1 k-steps (Cin / 32); NP2: channel-tile pairs of cv2 per workgroup (Cout / SPLIT / 32): 2 or 4
@@ -42,19 +50,31 @@ __global__ __launch_bounds__(SPPF_NW * 64) void sppf_fused_kernel(const SppfArgs
     constexpr int NG2 = SPPF_NW / NP2;                 // pixel groups of the cv2 phases
     constexpr int MAXJ2 = (SPPF_MAXPX / 16 + NG2 - 1) / NG2;
     constexpr int MAXJ1 = 3;                           // cv1: 4 tile pairs x 4 pixel groups, up to 11 pixel tiles
+    constexpr int NT = SPPF_NW * 64;
+    constexpr int NIT = (SPPF_MAXPX * 16 + NT - 1) / NT;   // (pixel, 16-byte channel group) items per thread of a pool pass
     const int HW = a.H * a.W, NCT = (HW + 15) >> 4;
     const int XP = a.Cin * 2 + 32;
-    unsigned char* ltrue = smem;
-    unsigned char* lt0 = smem + SPPF_MAXPX * SPPF_TP;
-    unsigned char* lt1 = lt0 + HW * 256;
-    unsigned char* lx = lt0;                           // the staged input aliases both pool buffers (and the slack behind them)
+    // LDS, phase 1 (cv1):   [ x: 176 pixels x XP | w1: all of cv1's weights, in the order they lie in HBM ]
+    //      phase 2 (pools): [ A | B | R ]  three maps of 176 x SPPF_TP bytes: A = the current source map as bf16 proper (what cv2's MFMAs read), B = the same map in the
+    //                       sortable domain (what the pool reads), R = its row maxima (sortable)
+    unsigned char* lx = smem;
+    unsigned char* lw1 = smem + SPPF_MAXPX * XP;
+    unsigned char* lt0 = smem;
+    unsigned char* lt1 = smem + SPPF_MAXPX * SPPF_TP;
+    unsigned char* lr = smem + 2 * SPPF_MAXPX * SPPF_TP;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int p = lane & 15, kq = lane >> 4;
     const int part = blockIdx.x, f = blockIdx.y;
+#ifdef ZLY_SPPF_DIAG
+    unsigned long long dsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dT0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long dstart = dT0;
+#endif
 
-    // ---- x -> LDS (LDS-DMA; padding pieces, pixels beyond the map and units beyond the tile get an out-of-range offset: zeros) ----
+    // ---- x and cv1's weights -> LDS by LDS-DMA, every byte once per workgroup (round 4 v1 had each wave fetch its tile pair's 16 KB of weights itself:
+    //      four waves per pair, 256 KB through the CU's vector memory path = most of the 7.5 k cycles this phase took).  Padding pieces, pixels beyond the
+    //      map and units beyond the tile get an out-of-range offset: zeros. ----
     {
         const bf16_t* xin = static_cast<const bf16_t*>(a.x) + a.x_co;
         const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(xin), 0, (unsigned)(((size_t)a.n * HW * a.x_cs - a.x_co) * 2), 0x00020000);
@@ -66,19 +86,15 @@ __global__ __launch_bounds__(SPPF_NW * 64) void sppf_fused_kernel(const SppfArgs
             const int q = (int)(((float)u + 0.5f) * inv_upitch), pc = u - q * upitch;
             const bool ok = pc < upp && q < HW;
             const unsigned off = ok ? (unsigned)(((f * HW + q) * a.x_cs) * 2 + pc * 16) : 0x80000000u;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)(lx + k * 1024), 16, off, 0, 0, 0);
+            if (q < NCT * 16)                              // lanes beyond x's last row write nothing (EXEC-masked): cv1's weights lie right behind it
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)(lx + k * 1024), 16, off, 0, 0, 0);
         }
+        const int w1_bytes = (SPPF_C / 16) * NK1 * 1024;
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w1), 0, (unsigned)w1_bytes, 0x00020000);
+        for (int k = wave; k < w1_bytes / 1024; k += SPPF_NW)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(lw1 + k * 1024), 16, (unsigned)(k * 1024 + lane * 16), 0, 0, 0);
     }
-    // ---- cv1: this wave's pair of channel tiles, every k-step, in registers (requested while the DMA is in flight) ----
     const int g1 = wave & 3, pg1 = wave >> 2;
-    bf16x8 w1[2][NK1];
-    {
-        const bf16_t* wb = static_cast<const bf16_t*>(a.w1) + lane * 8;
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int s = 0; s < NK1; ++s) w1[t][s] = *reinterpret_cast<const bf16x8*>(wb + ((size_t)(g1 * 2 + t) * NK1 + s) * 512);
-    }
     const f32x4 b1lo = *reinterpret_cast<const f32x4*>(a.b1 + g1 * 32 + kq * 8), b1hi = *reinterpret_cast<const f32x4*>(a.b1 + g1 * 32 + kq * 8 + 4);
     // cv2: tile pair g2 of this workgroup's share, pixel group pg2
     const int g2 = wave % NP2, pg2 = wave / NP2;
@@ -91,102 +107,135 @@ __global__ __launch_bounds__(SPPF_NW * 64) void sppf_fused_kernel(const SppfArgs
 #pragma unroll
             for (int k = 0; k < SPPF_KC; ++k) w[t][k] = *reinterpret_cast<const bf16x8*>(w2b + ((size_t)(pair2 * 2 + t) * nk2 + s * SPPF_KC + k) * 512);
     };
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of x have landed (and its weights)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces have landed
     __syncthreads();
+    SPPFSTAMP(0);
 
+    // ---- cv1: 4 tile pairs x 4 pixel groups; weight and pixel fragments from LDS ----
+    bf16x8 w2[2][SPPF_KC];
+    bf16x8 yv[MAXJ1];
     {
         f32x4 acc[MAXJ1][2];
 #pragma unroll
         for (int jj = 0; jj < MAXJ1; ++jj) { acc[jj][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[jj][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        const unsigned char* wl = lw1 + (size_t)(g1 * 2) * NK1 * 1024 + lane * 16;
 #pragma unroll
-        for (int s = 0; s < NK1; ++s)
+        for (int s = 0; s < NK1; ++s) {
+            const bf16x8 wa = *reinterpret_cast<const bf16x8*>(wl + s * 1024), wb = *reinterpret_cast<const bf16x8*>(wl + (NK1 + s) * 1024);
 #pragma unroll
             for (int jj = 0; jj < MAXJ1; ++jj) {
-                const int j = min(pg1 + jj * 4, NCT - 1);          // a missing tile recomputes the last one (never stored twice differently: same values)
+                const int j = min(pg1 + jj * 4, NCT - 1);          // a missing tile recomputes the last one; its result is dropped
                 const bf16x8 xf = *reinterpret_cast<const bf16x8*>(lx + (j * 16 + p) * XP + s * 64 + kq * 16);
-                acc[jj][0] = mma_step(w1[0][s], xf, acc[jj][0]);
-                acc[jj][1] = mma_step(w1[1][s], xf, acc[jj][1]);
+                acc[jj][0] = mma_step(wa, xf, acc[jj][0]);
+                acc[jj][1] = mma_step(wb, xf, acc[jj][1]);
             }
+        }
+        load_w2(0, w2);                                    // cv2's first weights are on their way while the epilogue runs
 #pragma unroll
         for (int jj = 0; jj < MAXJ1; ++jj) {
-            const int j = pg1 + jj * 4;
-            if (j >= NCT) continue;
             f32x4 lo = acc[jj][0] + b1lo, hi = acc[jj][1] + b1hi;
 #pragma unroll
             for (int r = 0; r < 4; ++r) { lo[r] = silu<bf16_t>(lo[r]); hi[r] = silu<bf16_t>(hi[r]); }
-            *reinterpret_cast<bf16x8*>(ltrue + (j * 16 + p) * SPPF_TP + (g1 * 32 + kq * 8) * 2) = to_bf16x8(lo, hi);     // lanes beyond the map write rows nobody pools (< 176)
+            yv[jj] = to_bf16x8(lo, hi);
         }
     }
-    bf16x8 w2[2][SPPF_KC];
-    load_w2(0, w2);                                        // cv2's first weights land while y goes to the sortable domain (not earlier: cv1's 64 weight registers are live until here)
-    __syncthreads();                                       // x is dead, y is whole
+    SPPFSTAMP(1);
+    __syncthreads();                                       // every wave has read its last fragment of x / w1: their space becomes T0 | T1 | R
+    bf16_t* cat = static_cast<bf16_t*>(a.cat);
+#pragma unroll
+    for (int jj = 0; jj < MAXJ1; ++jj) {
+        const int j = pg1 + jj * 4, q = j * 16 + p;
+        if (j >= NCT) continue;
+        // y as it is (A) and in the sortable domain (B); lanes beyond the map write rows nobody pools (< 176)
+        *reinterpret_cast<bf16x8*>(lt0 + q * SPPF_TP + (g1 * 32 + kq * 8) * 2) = yv[jj];
+        *reinterpret_cast<u32x4*>(lt1 + q * SPPF_TP + (g1 * 32 + kq * 8) * 2) = sortable(__builtin_bit_cast(u32x4, yv[jj]));
+        if (a.dump && part == 0 && q < HW) *reinterpret_cast<bf16x8*>(cat + ((size_t)(f * HW + q) * a.cat_cs + g1 * 32 + kq * 8)) = yv[jj];
+    }
+    __syncthreads();
+    SPPFSTAMP(2);
 
     const float invW = 1.0f / (float)a.W;
-    bf16_t* cat = static_cast<bf16_t*>(a.cat);
-    // y -> sortable domain (and, with the debug taps, to the concat buffer in HBM)
-    for (int u = tid; u < HW * 16; u += SPPF_NW * 64) {
-        const int q = u >> 4, pc = u & 15;
-        const u32x4 v = *reinterpret_cast<const u32x4*>(ltrue + q * SPPF_TP + pc * 16);
-        *reinterpret_cast<u32x4*>(lt0 + q * 256 + pc * 16) = sortable(v);
-        if (a.dump && part == 0) *reinterpret_cast<u32x4*>(cat + ((size_t)(f * HW + q) * a.cat_cs + pc * 8)) = v;
-    }
-
     f32x4 acc2[MAXJ2][2];
 #pragma unroll
     for (int jj = 0; jj < MAXJ2; ++jj) { acc2[jj][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[jj][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    unsigned char* tin = lt0;
-    unsigned char* tout = lt1;
+    unsigned char* const la = lt0;                          // A: bf16 proper
+    unsigned char* const lb = lt1;                          // B: sortable
 #pragma unroll 1
     for (int s = 0; s < 4; ++s) {
-        // ---- cv2 over source map s (TRUE) ----
+        // ---- cv2 over source map s (A) ----
 #pragma unroll
         for (int k = 0; k < SPPF_KC; ++k)
 #pragma unroll
             for (int jj = 0; jj < MAXJ2; ++jj) {
                 const int j = min(pg2 + jj * NG2, NCT - 1);
-                const bf16x8 xf = *reinterpret_cast<const bf16x8*>(ltrue + (j * 16 + p) * SPPF_TP + k * 64 + kq * 16);
+                const bf16x8 xf = *reinterpret_cast<const bf16x8*>(la + (j * 16 + p) * SPPF_TP + k * 64 + kq * 16);
                 acc2[jj][0] = mma_step(w2[0][k], xf, acc2[jj][0]);
                 acc2[jj][1] = mma_step(w2[1][k], xf, acc2[jj][1]);
             }
+        SPPFSTAMP(3);
         if (s == 3) break;
         load_w2(s + 1, w2);                                // the next source's weights land while the pool runs
-        __syncthreads();                                   // every wave is done with TRUE: it becomes the row-maxima buffer
-        // ---- pool stage s + 1: rows (tin -> TRUE region, pitch SPPF_TP), then columns (-> tout), both in the sortable domain ----
-        for (int u = tid; u < HW * 16; u += SPPF_NW * 64) {
-            const int q = u >> 4, pc = u & 15;
-            const int y = (int)(((float)q + 0.5f) * invW), x = q - y * a.W;
-            const unsigned char* row = tin + pc * 16;
-            s16x8 m = *reinterpret_cast<const s16x8*>(row + q * 256);
+        // ---- pool stage s + 1, rows: B -> R.  No barrier in front: the phase above only reads A, and R's last readers left through the barrier
+        //      that ended the previous stage.  A thread's items are all requested before the first max (one LDS round trip per pass, not three). ----
+#pragma unroll 1
+        for (int it0 = 0; it0 < NIT; it0 += 2) {               // two items per round: 40 registers of fragments in flight (three would spill beside w2 and the accumulators)
+            s16x8 v[2][5];
+            int qs[2], pcs[2];
 #pragma unroll
-            for (int d = 1; d <= 2; ++d) {
-                if (x - d >= 0) m = __builtin_elementwise_max(m, *reinterpret_cast<const s16x8*>(row + (q - d) * 256));
-                if (x + d < a.W) m = __builtin_elementwise_max(m, *reinterpret_cast<const s16x8*>(row + (q + d) * 256));
-            }
-            *reinterpret_cast<s16x8*>(ltrue + q * SPPF_TP + pc * 16) = m;
-        }
-        __syncthreads();
-        for (int u = tid; u < HW * 16; u += SPPF_NW * 64) {
-            const int q = u >> 4, pc = u & 15;
-            const int y = (int)(((float)q + 0.5f) * invW);
-            const unsigned char* col = ltrue + pc * 16;
-            s16x8 m = *reinterpret_cast<const s16x8*>(col + q * SPPF_TP);
+            for (int it = 0; it < 2; ++it) {
+                const int u = tid + (it0 + it) * NT;
+                const int q = min(u >> 4, HW - 1), pc = u & 15;
+                const int y = (int)(((float)q + 0.5f) * invW), x = q - y * a.W;
+                qs[it] = ((u >> 4) < HW && it0 + it < NIT) ? q : -1; pcs[it] = pc;
+                const unsigned char* row = lb + pc * 16;
 #pragma unroll
-            for (int d = 1; d <= 2; ++d) {
-                if (y - d >= 0) m = __builtin_elementwise_max(m, *reinterpret_cast<const s16x8*>(col + (q - d * a.W) * SPPF_TP));
-                if (y + d < a.H) m = __builtin_elementwise_max(m, *reinterpret_cast<const s16x8*>(col + (q + d * a.W) * SPPF_TP));
+                for (int d = -2; d <= 2; ++d) {
+                    const int qq = (x + d >= 0 && x + d < a.W) ? q + d : q;       // outside the row: the centre again (max is idempotent)
+                    v[it][d + 2] = *reinterpret_cast<const s16x8*>(row + qq * SPPF_TP);
+                }
             }
-            *reinterpret_cast<s16x8*>(tout + q * 256 + pc * 16) = m;
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const s16x8 m = __builtin_elementwise_max(__builtin_elementwise_max(__builtin_elementwise_max(v[it][0], v[it][1]), __builtin_elementwise_max(v[it][3], v[it][4])), v[it][2]);
+                if (qs[it] >= 0) *reinterpret_cast<s16x8*>(lr + qs[it] * SPPF_TP + pcs[it] * 16) = m;
+            }
         }
+        SPPFSTAMP(5);
         __syncthreads();
-        // ---- back into bf16 proper for the MFMA phase (T is its own inverse) ----
-        for (int u = tid; u < HW * 16; u += SPPF_NW * 64) {
-            const int q = u >> 4, pc = u & 15;
-            const u32x4 v = sortable(*reinterpret_cast<const u32x4*>(tout + q * 256 + pc * 16));
-            *reinterpret_cast<u32x4*>(ltrue + q * SPPF_TP + pc * 16) = v;
-            if (a.dump && part == 0) *reinterpret_cast<u32x4*>(cat + ((size_t)(f * HW + q) * a.cat_cs + (s + 1) * SPPF_C + pc * 8)) = v;
+        SPPFSTAMP(4);
+        // ---- columns: R -> B (sortable: the next stage's input) and A (mapped back: the next source of cv2).  Both are free: the row pass was B's last
+        //      reader, cv2's phase above A's, and every wave has passed the barrier behind them. ----
+#pragma unroll 1
+        for (int it0 = 0; it0 < NIT; it0 += 2) {
+            s16x8 v[2][5];
+            int qs[2], pcs[2];
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int u = tid + (it0 + it) * NT;
+                const int q = min(u >> 4, HW - 1), pc = u & 15;
+                const int y = (int)(((float)q + 0.5f) * invW);
+                qs[it] = ((u >> 4) < HW && it0 + it < NIT) ? q : -1; pcs[it] = pc;
+                const unsigned char* col = lr + pc * 16;
+#pragma unroll
+                for (int d = -2; d <= 2; ++d) {
+                    const int qq = (y + d >= 0 && y + d < a.H) ? q + d * a.W : q;
+                    v[it][d + 2] = *reinterpret_cast<const s16x8*>(col + qq * SPPF_TP);
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const s16x8 m = __builtin_elementwise_max(__builtin_elementwise_max(__builtin_elementwise_max(v[it][0], v[it][1]), __builtin_elementwise_max(v[it][3], v[it][4])), v[it][2]);
+                if (qs[it] >= 0) {
+                    const u32x4 tv = sortable(__builtin_bit_cast(u32x4, m));
+                    *reinterpret_cast<s16x8*>(lb + qs[it] * SPPF_TP + pcs[it] * 16) = m;
+                    *reinterpret_cast<u32x4*>(la + qs[it] * SPPF_TP + pcs[it] * 16) = tv;
+                    if (a.dump && part == 0) *reinterpret_cast<u32x4*>(cat + ((size_t)(f * HW + qs[it]) * a.cat_cs + (s + 1) * SPPF_C + pcs[it] * 8)) = tv;
+                }
+            }
         }
+        SPPFSTAMP(6);
         __syncthreads();
-        unsigned char* t = tin; tin = tout; tout = t;
+        SPPFSTAMP(7);
     }
     // ---- cv2 epilogue ----
     const int ch = pair2 * 32 + kq * 8;
@@ -201,13 +250,21 @@ __global__ __launch_bounds__(SPPF_NW * 64) void sppf_fused_kernel(const SppfArgs
         for (int r = 0; r < 4; ++r) { lo[r] = silu<bf16_t>(lo[r]); hi[r] = silu<bf16_t>(hi[r]); }
         *reinterpret_cast<bf16x8*>(out + ((size_t)(f * HW + q) * a.out_cs + a.out_co + ch)) = to_bf16x8(lo, hi);
     }
+#ifdef ZLY_SPPF_DIAG
+    if (lane == 0 && g_sppf_diag) {
+        unsigned long long* o = g_sppf_diag + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * SPPF_NW + wave) * 16;
+        for (int i = 0; i < 8; ++i) o[i] = dsum[i];
+        o[8] = __builtin_amdgcn_s_memtime() - dstart;
+    }
+#endif
 }
 
 static size_t sppf_lds_bytes(int cin, int hw)
 {
-    const size_t nct = (size_t)(hw + 15) / 16;
-    const size_t xb = nct * 16 * ((size_t)cin * 2 + 32), tb = 2 * (size_t)hw * 256;
-    return (size_t)SPPF_MAXPX * SPPF_TP + (xb > tb ? xb : tb);
+    (void)hw;
+    const size_t phase1 = (size_t)SPPF_MAXPX * ((size_t)cin * 2 + 32) + (size_t)(SPPF_C / 16) * (cin / 32) * 1024;      // x | cv1's weights
+    const size_t phase2 = (size_t)3 * SPPF_MAXPX * SPPF_TP;                                                           // T0 | T1 | R
+    return phase1 > phase2 ? phase1 : phase2;
 }
 
 typedef void (*sppf_fn)(const SppfArgs);
