@@ -16,7 +16,7 @@ KERNELS  := $(CSRC)/kernels_conv.hip $(CSRC)/kernels_pair.hip $(CSRC)/kernels_mi
 ENGINE   := $(CSRC)/engine.cpp $(CSRC)/weights.cpp
 OBJS     := $(OUT)/kernels_conv.o $(OUT)/kernels_pair.o $(OUT)/kernels_misc.o $(OUT)/kernels_head.o $(OUT)/kernels_stem.o $(OUT)/kernels_post.o $(OUT)/kernels_c2f64.o $(OUT)/kernels_sppf.o $(OUT)/engine.o $(OUT)/weights.o
 
-all: $(OUT)/libzly.so $(OUT)/libzly_gather.so $(OUT)/test_gather oracle weights host
+all: $(OUT)/libzly.so $(OUT)/libzly_gather.so $(OUT)/test_gather $(OUT)/zly_sharded_bench oracle weights host
 
 $(OUT):
 	mkdir -p $(OUT)
@@ -49,8 +49,16 @@ $(OUT)/libzly_gather.so: $(CSRC)/gather.cpp include/zly_gather.h | $(OUT)
 $(OUT)/test_gather: tests/cpp/test_gather.cpp $(OUT)/libzly_gather.so $(OUT)/libzly.so
 	$(HIPCC) --offload-arch=$(ARCH) -O2 -std=c++17 -Wno-unused-value -Iinclude -x hip tests/cpp/test_gather.cpp -o $@ -L$(OUT) -lzly_gather -lzly -Wl,-rpath,'$$ORIGIN'
 
+# the product caller of the gather library: one process, N GPUs in lock step (host/zly_sharded.hpp), as a bench / check tool
+$(OUT)/zly_sharded_bench: $(PKG)/tools/bench_sharded.cpp $(HOST)/zly_sharded.hpp $(HOST)/zly_sharded_hip.hpp $(HOST)/zly_compat.hpp include/zly.h include/zly_gather.h $(OUT)/libzly_gather.so $(OUT)/libzly.so
+	$(HIPCC) --offload-arch=$(ARCH) -O2 -std=c++17 -Wno-unused-value -Iinclude -I$(HOST) -x hip $(PKG)/tools/bench_sharded.cpp -o $@ -L$(OUT) -lzly_gather -lzly -Wl,-rpath,'$$ORIGIN'
+
+# ... and its host logic against stubs of both C ABIs and of the device runtime (test infrastructure: no GPU, no libzly.so)
+$(OUT)/test_sharded_stub: tests/cpp/test_sharded_stub.cpp $(HOST)/zly_sharded.hpp $(HOST)/zly_compat.hpp include/zly.h include/zly_gather.h | $(OUT)
+	$(CXX) -O2 -std=c++17 -Wall -Iinclude -I$(HOST) -o $@ tests/cpp/test_sharded_stub.cpp
+
 # ---- host side: the reference's IInferenceEngine plugin interface over the C ABI -----------------
-host: $(OUT)/libzly_plugin.so $(OUT)/test_hip_engine $(OUT)/test_wire $(OUT)/test_game_step $(OUT)/test_frame_server $(OUT)/zly_h2h_bench $(OUT)/test_plugin_stub
+host: $(OUT)/libzly_plugin.so $(OUT)/test_hip_engine $(OUT)/test_wire $(OUT)/test_game_step $(OUT)/test_frame_server $(OUT)/zly_h2h_bench $(OUT)/test_plugin_stub $(OUT)/test_sharded_stub
 
 $(OUT)/libzly_plugin.so: $(HOST)/hip_inference_engine.cpp $(HOST)/hip_inference_engine.h $(HOST)/zly_sha256.hpp $(HOST)/zly_compat.hpp include/zly.h $(OUT)/libzly.so
 	$(CXX) -O2 -std=c++17 -fPIC -shared -Iinclude -I$(HOST) -o $@ $(HOST)/hip_inference_engine.cpp -L$(OUT) -lzly -pthread -Wl,-rpath,'$$ORIGIN'

@@ -479,7 +479,7 @@ def run():
             roof[B]["launches_with_frac_above_1"] = bad
             # HBM-side traffic of the same kernels from the PMC counters (collected off-line with rocprofv3, two
             # --pmc passes, gfx950 correction applied; see the file for provenance): per batch-64 step
-            for tp in ("r03_traffic_b64.json", "r02_traffic_b64.json"):
+            for tp in ("r04_traffic_b64.json", "r03_traffic_b64.json", "r02_traffic_b64.json"):
                 tpath = os.path.join(ROOT, "profiles", tp)
                 if B == 64 and default_cfg and os.path.exists(tpath):
                     tj = json.load(open(tpath))

@@ -56,7 +56,7 @@ extern "C" {
 #define ZLY_ERR_MODEL_LOAD      202
 #define ZLY_ERR_INVALID_INPUT   203
 #define ZLY_ERR_SYSTEM          300
-#define ZLY_PENDING             1   /* zly_poll only: the ticket's batch has not completed yet (not an error) */
+#define ZLY_PENDING             1   /* zly_poll: the ticket's batch has not completed yet; zly_submit_try: every ring slot is busy (neither is an error) */
 
 #define ZLY_DTYPE_FP32 0   /* fp32 activations + exact-fp32 MFMA: verification mode */
 #define ZLY_DTYPE_BF16 1   /* bf16 activations/weights, fp32 accumulate: production mode */
@@ -158,7 +158,7 @@ int32_t zly_detect_batch(zly_engine* e, int32_t n, const uint8_t* const* bgr, co
 
 /* --- asynchronous, pipelined host-to-host path ------------------------------------------------------
  * The throughput path of a server: many host threads hand over frames, the engine batches them and overlaps the PCIe
- * transfers with compute.  Engine-owned ring of pinned staging slots (ZLY_STAGE_SLOTS, default 4; each holds one batch of
+ * transfers with compute.  Engine-owned ring of pinned staging slots (ZLY_STAGE_SLOTS, default 6; each holds one batch of
  * up to max_batch frames / ZLY_STAGE_MB megabytes, default 1.25 x max_batch model-sized frames):
  *   zly_submit   (any thread, concurrently) reserves a frame slot in the batch being filled and copies the pixels into
  *                pinned memory ON THE CALLING THREAD -- the one copy of the request the reference makes too

@@ -58,6 +58,9 @@ class YoloV8Ref:
         # that its pre-activation std hits a target; the factors are recorded in self.calib_scale.
         self.calib_target = None
         self.calib_scale: Dict[str, float] = {}
+        # fp8 study (tools/fp8_act_study.py only): convs whose INPUT activations are rounded to OCP e4m3 with one power-of-two scale per tensor before
+        # the conv -- what a v_mfma_f32_16x16x128_f8f6f4 path with activations quantised in the producer's epilogue would compute (BASELINE configs[4])
+        self.fp8_act = None                     # predicate: conv name -> bool
 
     # -- building blocks ---------------------------------------------------------------------
     def _q(self, t):
@@ -66,6 +69,14 @@ class YoloV8Ref:
     def conv(self, name, x, residual=None, keep_fp32=False):
         c = self.spec[name]
         w, b = self.w[name]
+        if self.fp8_act is not None and self.fp8_act(name):
+            if getattr(self, "fp8_per_channel", False):                              # one power-of-two scale per input channel (what a per-channel epilogue scale could give)
+                amax = x.abs().amax(dim=(0, 2, 3), keepdim=True).clamp_min(1e-30)
+                sc = torch.exp2(torch.floor(torch.log2(448.0 / amax)))
+            else:
+                amax = float(x.abs().max())
+                sc = 2.0 ** np.floor(np.log2(448.0 / amax)) if amax > 0 else 1.0      # e4m3fn: largest finite value 448
+            x = (x * sc).to(torch.float8_e4m3fn).to(torch.float32) / sc
         y = F.conv2d(x, w, b, stride=c.stride, padding=c.k // 2)
         if self.calib_target is not None:
             tgt = self.calib_target(name)

@@ -94,7 +94,8 @@ Result<void> HipInferenceEngine::initialize()
     model_version_ = 1;
     {
         std::lock_guard<std::mutex> lk(queue_mutex_);
-        pending_.clear();                                      // nothing of a previous run may be emitted under the new sequence numbers
+        pending_.assign((size_t)(ndev * engines_per_gpu_) + 1, std::deque<Pending>());     // nothing of a previous run may be emitted under the new sequence numbers
+        pending_count_ = 0;
         ring_.assign(1024, Done{});
         ring_full_.assign(1024, 0);
         finished_count_ = 0;
@@ -256,8 +257,9 @@ Result<void> HipInferenceEngine::shutdown()
     if (reaper_.joinable()) reaper_.join();
     {
         std::lock_guard<std::mutex> lk(queue_mutex_);
-        dropped_frames_ += pending_.size();
-        pending_.clear();                                       // stale results must never be emitted by a later initialize()
+        dropped_frames_ += pending_count_;
+        for (auto& q : pending_) q.clear();                     // stale results must never be emitted by a later initialize()
+        pending_count_ = 0;
         ring_.clear(); ring_full_.clear(); finished_count_ = 0;
     }
     std::vector<std::shared_ptr<EngineHandle>> old;
@@ -296,10 +298,12 @@ Result<void> HipInferenceEngine::submitInference(const InferenceRequest& request
             const size_t ne = snap->size(), first = (size_t)(seq % ne);
             int32_t rc = ZLY_PENDING;
             for (size_t k = 0; k < ne && rc == ZLY_PENDING; ++k) {
-                p.engine = (*snap)[(first + k) % ne];
+                p.slot = (first + k) % ne;
+                p.engine = (*snap)[p.slot];
                 rc = zly_submit_try(p.engine->e, request.data.data(), request.data.size(), request.width, request.height, &p.ticket);
             }
             if (rc == ZLY_PENDING) {
+                p.slot = first;
                 p.engine = (*snap)[first];
                 rc = zly_submit(p.engine->e, request.data.data(), request.data.size(), request.width, request.height, &p.ticket);
             }
@@ -310,9 +314,12 @@ Result<void> HipInferenceEngine::submitInference(const InferenceRequest& request
     bool wake;
     {
         std::lock_guard<std::mutex> lk(queue_mutex_);
-        wake = pending_.empty();                                 // the completion thread only sleeps on an empty queue
-        pending_.push_back(std::move(p));
-        const size_t depth = pending_.size() + finished_count_;
+        if (pending_.empty()) return Result<void>::error(ErrorCode::NOT_INITIALIZED, "Engine not running");     // shutdown() got in between
+        wake = pending_count_ == 0;                              // the completion thread only sleeps on empty queues
+        const size_t qi = (p.failed || p.simulated) ? pending_.size() - 1 : std::min(p.slot, pending_.size() - 2);
+        pending_[qi].push_back(std::move(p));
+        ++pending_count_;
+        const size_t depth = (size_t)(seq + 1 - next_emit_);
         if (depth > queue_high_water_mark_) queue_high_water_mark_ = depth;
     }
     if (wake) queue_cv_.notify_one();
@@ -328,7 +335,7 @@ void HipInferenceEngine::setCallback(InferenceCallback callback)
 size_t HipInferenceEngine::getQueueSize() const
 {
     std::lock_guard<std::mutex> lk(queue_mutex_);
-    return pending_.size() + finished_count_;
+    return (size_t)(next_seq_.load() - next_emit_);              // submitted, not yet handed to the callback (or dropped as failed)
 }
 
 std::string HipInferenceEngine::getName() const { return "hip"; }
@@ -366,50 +373,66 @@ std::vector<Detection> HipInferenceEngine::generateRandomDetections()
 void HipInferenceEngine::completionLoop()
 {
     std::vector<zly_det> dets((size_t)max_dets_);
-    std::deque<Pending> local;
+    std::vector<std::deque<Pending>> local;                     // per engine slot (the last queue: requests without a ticket), in ticket order
+    size_t local_count = 0;
     std::vector<std::pair<uint64_t, Done>> group;               // (sequence number, result) of the frames completed in this round
     std::vector<Done> ready;
-    while (true) {
-        if (local.empty()) {
-            std::unique_lock<std::mutex> lk(queue_mutex_);
-            queue_cv_.wait_for(lk, std::chrono::milliseconds(100), [&] { return !pending_.empty() || !running_; });
-            if (pending_.empty()) {
-                if (!running_) return;                           // shutting down: everything already in the ring has been handed over
-                continue;
+    auto take = [&](Pending& p) {                               // consume one request whose result is available (or whose batch this call waits for)
+        Done d;
+        d.client_id = p.client_id; d.enqueue_ms = p.enqueue_ms;
+        if (p.simulated) {
+            d.ok = true;
+            d.state.frame_id = p.frame_id; d.state.timestamp = p.timestamp;
+            d.state.detections = generateRandomDetections();
+        } else if (!p.failed) {
+            int32_t n = 0;
+            const int32_t rc = zly_wait(p.engine->e, p.ticket, dets.data(), max_dets_, &n);
+            if (rc == ZLY_OK) {
+                d.ok = true;
+                d.state.frame_id = p.frame_id;                   // onnx_engine.cpp:520-521
+                d.state.timestamp = p.timestamp;
+                const int cnt = std::min<int>(n, max_dets_);
+                static_assert(sizeof(zly_det) == sizeof(Detection), "zly_det must be layout-identical to Detection");
+                d.state.detections.resize((size_t)cnt);
+                if (cnt) std::memcpy(d.state.detections.data(), dets.data(), (size_t)cnt * sizeof(Detection));
+            } else {
+                inference_errors_++;
             }
-            local.swap(pending_);
+            release(std::move(p.engine));                        // an engine replaced by a reload goes with its last request -- on the reaper thread
+        }
+        group.emplace_back(p.seq, std::move(d));
+    };
+    while (true) {
+        {
+            std::unique_lock<std::mutex> lk(queue_mutex_);
+            if (local_count == 0) {
+                queue_cv_.wait_for(lk, std::chrono::milliseconds(100), [&] { return pending_count_ != 0 || !running_; });
+                if (pending_count_ == 0) {
+                    if (!running_) return;                       // shutting down: everything already in the rings has been handed over
+                    continue;
+                }
+            }
+            if (local.size() != pending_.size()) local.resize(pending_.size());
+            for (size_t i = 0; i < pending_.size(); ++i)         // everything that is pending, under ONE lock
+                while (!pending_[i].empty()) { local[i].push_back(std::move(pending_[i].front())); pending_[i].pop_front(); ++local_count; }
+            pending_count_ = 0;
         }
         group.clear();
-        bool first = true;
-        while (!local.empty()) {
-            Pending& p = local.front();
-            // the first request of a round may block for its batch; the ones behind it are taken only if their batch is back too
-            if (!first && !p.failed && !p.simulated && zly_poll(p.engine->e, p.ticket) != ZLY_OK) break;
-            first = false;
-            Done d;
-            d.client_id = p.client_id; d.enqueue_ms = p.enqueue_ms;
-            if (p.simulated) {
-                d.ok = true;
-                d.state.frame_id = p.frame_id; d.state.timestamp = p.timestamp;
-                d.state.detections = generateRandomDetections();
-            } else if (!p.failed) {
-                int32_t n = 0;
-                const int32_t rc = zly_wait(p.engine->e, p.ticket, dets.data(), max_dets_, &n);
-                if (rc == ZLY_OK) {
-                    d.ok = true;
-                    d.state.frame_id = p.frame_id;               // onnx_engine.cpp:520-521
-                    d.state.timestamp = p.timestamp;
-                    const int cnt = std::min<int>(n, max_dets_);
-                    static_assert(sizeof(zly_det) == sizeof(Detection), "zly_det must be layout-identical to Detection");
-                    d.state.detections.resize((size_t)cnt);
-                    if (cnt) std::memcpy(d.state.detections.data(), dets.data(), (size_t)cnt * sizeof(Detection));
-                } else {
-                    inference_errors_++;
-                }
-                release(std::move(p.engine));                    // an engine replaced by a reload goes with its last request -- on the reaper thread
+        // every engine's tickets whose batch is back, without blocking (requests without a ticket are always ready)
+        for (size_t i = 0; i < local.size(); ++i)
+            while (!local[i].empty()) {
+                Pending& p = local[i].front();
+                if (!p.failed && !p.simulated && zly_poll(p.engine->e, p.ticket) != ZLY_OK) break;
+                take(p);
+                local[i].pop_front(); --local_count;
             }
-            group.emplace_back(p.seq, std::move(d));
-            local.pop_front();
+        if (group.empty() && local_count != 0) {
+            // nothing is back yet: wait for the oldest request's batch (the one the callback order needs first)
+            size_t best = local.size();
+            for (size_t i = 0; i < local.size(); ++i)
+                if (!local[i].empty() && (best == local.size() || local[i].front().seq < local[best].front().seq)) best = i;
+            take(local[best].front());
+            local[best].pop_front(); --local_count;
         }
         // hand over in submission order
         ready.clear();

@@ -70,6 +70,7 @@ private:
         bool simulated = false;                            // ZLY_SIMULATE=1: no engine, no ticket; the completion thread draws the reference's random boxes
         uint32_t client_id = 0, frame_id = 0;
         uint64_t timestamp = 0, enqueue_ms = 0;
+        size_t slot = 0;                                   // index of its queue in pending_
     };
 
     void completionLoop();
@@ -111,7 +112,11 @@ private:
     // Requests whose pixels are in the engine's ring, in the order zly_submit returned: the completion thread consumes them in
     // THIS order (never in sequence order: the owner of the next sequence number may be blocked in zly_submit by ring
     // back-pressure that only consuming later tickets releases), and re-orders the results by sequence number for the callback.
-    std::deque<Pending> pending_;
+    // One queue per engine slot (+ one for requests without a ticket: refused or simulated): the completion thread drains whichever engine's batch is back
+    // first.  One global queue made it consume tickets in push order, i.e. alternately from all engines: a finished batch of engine A stayed unconsumed --
+    // its ring slot unrecycled, A's submitters back-pressured -- until the interleaved tickets of engine B's still running batch had been waited for.
+    std::vector<std::deque<Pending>> pending_;
+    size_t pending_count_ = 0;
     // results waiting for an earlier sequence number: a ring indexed by seq & (size - 1), grown when the span of outstanding sequence numbers exceeds it
     // (round 3: a std::map insert + erase per frame).  Touched by the completion thread under queue_mutex_ once per GROUP of completed frames.
     std::vector<Done> ring_;

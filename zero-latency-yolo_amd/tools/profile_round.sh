@@ -3,7 +3,7 @@
 #   kernel trace + stats of ONE engine's chain (--engines 1: per-position table, one-step timeline), kernel stats of the default
 #   three-engine headline, PMC traffic (two passes, one engine)
 set -e
-tag=${1:-r03}
+tag=${1:-r04}
 out=gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
@@ -25,6 +25,12 @@ PY
 )
 python3 zero-latency-yolo_amd/tools/trace_summary.py "$kt" $n $out/per_position.txt
 python3 zero-latency-yolo_amd/tools/trace_timeline.py "$kt" 3 > $out/timeline.txt
+# the latency path (batch 1, one engine): per-dispatch begin / end / gap of one step, and the kernel stats
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt1 -- python3 bench.py --batch 1 --steps 200 --warmup 20 --blocks 2 --no-extras --no-cpu-baseline --engines 1 > $out/kt1_bench.json 2> $out/kt1.err
+kt1=$(find $out/kt1 -name "*kernel_trace.csv" | head -1)
+cp "$(find $out/kt1 -name '*kernel_stats.csv' | head -1)" $out/kernel_stats_b1.csv
+python3 zero-latency-yolo_amd/tools/trace_timeline.py "$kt1" 5 > $out/timeline_b1.txt
+rm -rf $out/kt1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_r -- python3 bench.py --batch 64 --steps 6 --warmup 1 --blocks 1 --no-extras --no-cpu-baseline --engines 1 > /dev/null 2> $out/pmc_r.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_w -- python3 bench.py --batch 64 --steps 6 --warmup 1 --blocks 1 --no-extras --no-cpu-baseline --engines 1 > /dev/null 2> $out/pmc_w.err
 python3 zero-latency-yolo_amd/tools/pmc_traffic.py $out/pmc_r $out/pmc_w $out/traffic_b64.json

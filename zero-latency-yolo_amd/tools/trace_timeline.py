@@ -12,9 +12,16 @@ t0 = int(rows[i0]["Start_Timestamp"])
 step = rows[i0:i1 + 3]
 print(f"# step of {i1 - i0} dispatches, {(int(rows[i1]['Start_Timestamp']) - t0) / 1000:.1f} us to the next step's first kernel")
 ends = []
+dur_sum = gap_sum = 0.0
 for r in step:
     st, en = (int(r["Start_Timestamp"]) - t0) / 1000, (int(r["End_Timestamp"]) - t0) / 1000
     live = sum(1 for e in ends if e > st)
+    gap = st - max(ends) if ends else 0.0           # idle time between the end of everything launched before and this dispatch's begin (negative: overlap)
     ends.append(en)
+    if len(ends) <= i1 - i0:
+        dur_sum += en - st
+        gap_sum += max(gap, 0.0)
     name = r["Kernel_Name"].replace("zly::", "").replace("void ", "")[:58]
-    print(f"{st:8.1f} -> {en:8.1f}  ({en - st:6.1f} us)  +{live}  {name}")
+    print(f"{st:8.1f} -> {en:8.1f}  ({en - st:6.2f} us, gap {gap:+6.2f})  +{live}  {name}")
+print(f"# this step: sum of dispatch durations {dur_sum:.1f} us, sum of idle gaps between dispatches {gap_sum:.1f} us, {i1 - i0} dispatches "
+      f"-> {dur_sum / (i1 - i0):.2f} us inside a dispatch, {gap_sum / (i1 - i0):.2f} us between two on average")
