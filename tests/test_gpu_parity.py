@@ -356,7 +356,7 @@ def test_production_kernels_layerwise_vs_oracle(weights_path, oracle, ref_fp32, 
                                        (416, 416, 3, {"ZLY_WS1_NO_DUAL": "1"}), (352, 288, 5, {"ZLY_WS1": "2", "ZLY_WS1_MIN_PX": "1", "ZLY_WS1_MAX_BYTES": "1"}),
                                        (352, 288, 5, {"ZLY_NO_WS_S2": "1"}), (224, 416, 4, {"ZLY_NO_WS_S2": "1"}), (352, 288, 5, {"ZLY_NO_WS_S2_C32": "1"}),
                                        (352, 288, 5, {"ZLY_WS_MAX_BYTES": "1"}), (416, 416, 3, {"ZLY_STEM1_VAR": "0"}), (352, 288, 5, {"ZLY_STEM1_VAR": "0"}),
-                                       (416, 416, 3, {"ZLY_SPPF_FUSED": "1"}), (224, 416, 4, {"ZLY_SPPF_FUSED": "1"}), (352, 288, 5, {"ZLY_SPPF_FUSED": "1"})])
+                                       (416, 416, 3, {"ZLY_NO_WSK": "1"}), (352, 288, 5, {"ZLY_NO_WSK": "1"}), (416, 416, 3, {"ZLY_SPPF_FUSED": "1"}), (224, 416, 4, {"ZLY_SPPF_FUSED": "1"}), (352, 288, 5, {"ZLY_SPPF_FUSED": "1"})])
 def test_throughput_kernels_on_ragged_maps(weights_path, oracle, monkeypatch, w, h, n, env):
     """conv3x3_lds_kernel, conv1x1_stream_kernel and bottleneck_pair_kernel forced onto small batches of ragged maps (88x72 ..
     11x9, 104x104 .. 13x13, 56x104 .. 7x13: partial tiles on every edge, 13-row maps, last pixel groups that are not full,
@@ -395,6 +395,8 @@ def test_throughput_kernels_on_ragged_maps(weights_path, oracle, monkeypatch, w,
         assert "conv1x1_ws_kernel" not in kn, kn
     if "ZLY_C2F64" in env:
         assert "c2f_kernel<C=64" in kn, kn
+    # the 80 -> 80 class-branch convs: the K-packed five-wave kernel (ragged 13 x 13 tiles of 52 x 52 ... 7 x 13 maps here) unless switched off
+    assert ("conv3x3_wsk_kernel" in kn) == ("ZLY_NO_WSK" not in env and n > 4), kn        # batch <= 4: the Detect convs run as merged launches
     # SPPF: cv1 | pool | cv2 launches by default; ZLY_SPPF_FUSED=1: one launch (kernels_sppf.hip: 13 x 13, 7 x 13 and 11 x 9 maps here, split 4 ways by output channels)
     assert ("sppf_fused_kernel" in kn) == ("ZLY_SPPF_FUSED" in env), kn
     assert ("sppf_pool_kernel" in kn) == ("ZLY_SPPF_FUSED" not in env), kn

@@ -60,6 +60,14 @@ __device__ __forceinline__ void load8(const bf16_t* p, f32x4& a, f32x4& b) {
 }
 __device__ __forceinline__ void load8(const float* p, f32x4& a, f32x4& b) { a = *reinterpret_cast<const f32x4*>(p); b = *reinterpret_cast<const f32x4*>(p + 4); }
 
+// Hides a (constant) byte offset from the compiler, at no instruction: two 8-byte LDS reads a CONSTANT distance apart (the taps of a row: kx * pitch) are fused
+// into one ds_read2_b64, and that instruction is served like ds_write -- in groups of 16 lanes over 32 banks, at half the bytes per clock (MI355X guide, LDS
+// table) -- so a pixel pitch that is conflict-free for ds_read_b64 (two groups of 32 lanes over 64 banks: 48 B at stride 1, 40 B at stride 2) is 2-way
+// conflicted there.  Round 4 PMC: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.34 on c2f_kernel<16> and 0.23 on the front kernel came from exactly these reads.
+// With the tap offsets in registers of unknown value the reads stay single.  (A volatile access also prevents the fusion -- and serialises the reads: the
+// front kernel's last phase 2.9 k -> 5.5 k cycles, c2f_kernel<16>'s 3x3 phases 5 k -> 10 k: measured and dropped.)
+__device__ __forceinline__ int opaque_offset(int v) { asm("" : "+v"(v)); return v; }
+
 // Output-channel map of MFMA tile `tile` (global tile index), lane group kq: with the pair permutation of
 // weights.cpp (all tiles below `paired_tiles`) a lane holds channels g*32 + kq*8 + half*4 .. +3; otherwise
 // tile*16 + kq*4 .. +3.

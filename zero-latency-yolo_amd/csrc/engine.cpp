@@ -84,6 +84,8 @@ struct Op {
     double flops = 0, bytes = 0;
     double wbytes = 0;                 // weight + bias bytes of this op (part of `bytes`)
     double cin_frac = 1.0;             // real / stored input channels (the 3-of-8 channel image, the 80-of-96 channel class branch)
+    size_t wsk_w = 0;                  // the 80 -> 80 class-branch convs: weights once more, tiled with cin_store = 80 for conv3x3_wsk_kernel (K packed across taps); 0 = none
+    std::map<int, int> wsk_cache;      // batch size -> does that kernel take the launch
     std::map<int, ConvLaunch> launch_cache;    // batch size -> kernel shape of the per-conv path (conv_pick_config reads the environment: once per shape, not per launch)
 };
 
@@ -176,7 +178,7 @@ struct zly_engine {
     std::atomic<Ingest*> ingest{nullptr};   // created by the first zly_submit (under mu), read lock-free afterwards
 
     // tuning / test switches of the environment, read ONCE at zly_create (they used to be read per launch)
-    struct Switches { bool no_c2f = false, no_det_merge = false, no_tail_split = false, no_lanes = false, nms_general = false, no_sppf = false; int stem1_nw = 0, stem1_var = 1; std::string ablate; } sw;
+    struct Switches { bool no_c2f = false, no_det_merge = false, no_tail_split = false, no_lanes = false, nms_general = false, no_sppf = false, no_wsk = false; int stem1_nw = 0, stem1_var = 1; std::string ablate; } sw;
 
     std::mutex mu;                    // serialises every call that touches engine / device state
     mutable std::mutex stats_mu;      // guards `stats` only, never held across a device call: zly_get_stats cannot wait on a batch
@@ -510,6 +512,15 @@ static int build_plan_host(zly_engine* e, PlanState* ps, std::string* err)
         ok = ok && pb.conv({"model.22.cv2." + L + ".0", "model.22.cv3." + L + ".0"}, View{feats[l], 0, fch[l]}, View{hd1, 0, c2 + c3});
         ok = ok && pb.conv({"model.22.cv2." + L + ".1"}, View{hd1, 0, c2}, View{hb2, 0, c2});
         ok = ok && pb.conv({"model.22.cv3." + L + ".1"}, View{hd1, c2, c3s}, View{hc2, 0, c3});
+        if (ok && e->dtype == ZLY_DTYPE_BF16 && c3 == 80 && c3s >= 80) {
+            // the same conv for conv3x3_wsk_kernel: k = tap * 80 + c without channel padding (23 k-steps instead of 27), plain tile rows, no zero output tile
+            const ConvRec* r = m.find("model.22.cv3." + L + ".1");
+            std::vector<uint8_t> w;
+            std::vector<float> b;
+            int cout = 0, cout_pad = 0, nk = 0;
+            repack_conv({r}, 80, pb.kstep, true, &w, &b, &cout, &cout_pad, &nk, false);
+            if (nk == 23 && cout_pad == 80 && r->k == 3 && r->stride == 1) e->ops.back().wsk_w = pb.append(w.data(), w.size());
+        }
         HeadLevel& hl = hd.head.lv[l];
         ok = ok && pb.pack_only("model.22.cv2." + L + ".2", c2, &pend[l].wb, &pend[l].bb, &hl.nkb);
         ok = ok && pb.pack_only("model.22.cv3." + L + ".2", c3, &pend[l].wc, &pend[l].bc, &hl.nkc);
@@ -772,6 +783,19 @@ static int detect_merge_role(const zly_engine* e, int i)
     return 0;
 }
 
+// the 80 -> 80 class-branch conv on the K-packed weight-stationary kernel at this batch size?  (decided once per op and batch size)
+static bool wsk_active(zly_engine* e, const Op& op, int n)
+{
+    if (!op.wsk_w || e->sw.no_wsk || e->dtype != ZLY_DTYPE_BF16) return false;
+    Op& mop = const_cast<Op&>(op);
+    auto it = mop.wsk_cache.find(n);
+    if (it == mop.wsk_cache.end()) {
+        const Buffer& ob = e->bufs[(size_t)op.out.buf];
+        it = mop.wsk_cache.emplace(n, conv_wsk_ok(80, op.cout, n, ob.H, ob.W) ? 1 : 0).first;
+    }
+    return it->second != 0;
+}
+
 // SPPF as one launch (kernels_sppf.hip) at the block's first op; the pool and cv2 ops then launch nothing
 static bool sppf_active(const zly_engine* e)
 {
@@ -933,6 +957,13 @@ static hipError_t run_op(zly_engine* e, const Op& op, int n, const uint8_t* d_sr
             }
         }
         ConvArgs a = make_conv_args(e, op, n);
+        if (wsk_active(e, op, n)) {
+            ConvArgs k = a;
+            k.Cin = 80; k.K = 9 * 80; k.nk = 23; k.cout_pad = 80;
+            k.wgt = (const char*)e->d_weights + op.wsk_w;
+            const hipError_t r = launch_conv_wsk(k, s);
+            if (r != hipErrorInvalidValue) return r;             // a tensor beyond the kernel's 32-bit offsets takes the generic path below
+        }
         return launch_conv(e->dtype, a, conv_launch_of(e, op, n), s);
     }
     case OP_SPPF: {
@@ -1699,6 +1730,7 @@ int32_t zly_create(const zly_config* cfg, zly_engine** out)
     e->sw.no_tail_split = getenv("ZLY_NO_TAIL_SPLIT") != nullptr;
     e->sw.no_lanes = getenv("ZLY_NO_LANES") != nullptr || getenv("ZLY_CU_PART") != nullptr;
     e->sw.no_sppf = getenv("ZLY_SPPF_FUSED") == nullptr;                         // the fused SPPF kernel is OPT-IN (ZLY_SPPF_FUSED=1): parity-green, 36 -> ~24 us in isolation at batch 64, but the step gets 0.5 % slower
+    e->sw.no_wsk = getenv("ZLY_NO_WSK") != nullptr;                               // tuning / tests: the class-branch convs on the LDS-tiled kernel (96-channel padding)
     e->sw.nms_general = getenv("ZLY_NMS_GENERAL") != nullptr;                     // tests / A-B: every frame on NMS's eight-wave path
     if (const char* v = getenv("ZLY_STEM1_NW")) e->sw.stem1_nw = atoi(v);           // tuning aids: waves per workgroup of the front kernel (12 / 16), ...
     if (const char* v = getenv("ZLY_STEM1_VAR")) e->sw.stem1_var = atoi(v);         // ... and 0 = round 3's staging / tap order (A/B on one box)
@@ -2194,6 +2226,7 @@ int32_t zly_op_kernel_name(zly_engine* e, int32_t i, int32_t n, char* out, size_
             break;
         }
         if (op.pair && pair_active(e, op, n)) { k = op.pair == 1 ? "bottleneck_pair_kernel<" + std::to_string(op.pair_c) + ">" : "(fused into the previous launch)"; break; }
+        if (wsk_active(e, op, n)) { k = "conv3x3_wsk_kernel<K=720 packed across taps,5 channel tiles>"; break; }
         const int cin = op.in.C + (op.in2.buf >= 0 ? op.in2.C : 0);
         const ConvLaunch c = conv_launch_of(e, op, n);
         if (c.ws1) k = std::string("conv1x1_ws_kernel<") + (op.in2.buf >= 0 ? "dual-source," : "") + "NK=" + std::to_string(cin / 32) + "," + std::to_string(c.ct) + " channel tiles," + std::to_string(c.pt * 16) + " px>";

@@ -1126,6 +1126,211 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ws_kernel(const ConvArgs a, co
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------
+// The 80 -> 80 class-branch convs of Detect (model.22.cv3.L.1; nc = 80), weight-stationary with K PACKED ACROSS TAPS.
+//
+// Round 3 ran them on conv3x3_lds_kernel with the input stored as 96 channels and a sixth, all-zero output tile (27 k-steps x 6 tiles): 31 % of its
+// MFMAs and of its fragment traffic were on zeros (46.6 us at P3 for 8.8 us of attainable work).  conv3x3_ws_kernel cannot take them: two
+// tiles per wave x 27 k-steps is 216 weight registers, and one tile per wave leaves 5 tiles over 4 waves.  Here:
+//   * K runs over (tap, channel) without padding: k = tap * 80 + c, 720 = 22.5 k-steps of 32 -> NKS = 23.  Channels come in groups of 8 (one 16-byte
+//     fragment piece), 10 per tap, so a k-step's four lane groups sit in up to two taps: lane group kq of k-step s reads group G = 4 s + kq =
+//     (tap G / 10, piece G % 10) -- a PER-LANE patch offset, precomputed once (two 16-bit offsets per register);
+//   * a workgroup is FIVE waves, one per 16-channel output tile (plain tile rows: 8-byte NHWC stores), all walking the same pixel tile past their 92
+//     weight registers; two workgroups per CU (<= 168 VGPRs: three waves per SIMD);
+//   * everything else is conv3x3_ws_kernel: patch by LDS-DMA with the buffer range check as zero padding (pitch 80 * 2 B: wsk_plan), persistent over 13 x 13-ish
+//     tiles, column tiles in pairs, epilogue of a pair beside the next pair's MFMAs.
+// The input view is the first 80 of the 96 stored channels; the weights are tiled with cin_store = 80 (weights.cpp: k = tap * 80 + c, zero beyond 720).
+// ------------------------------------------------------------------------------------------------
+template <int NKS>
+__global__ __launch_bounds__(320, 3) void conv3x3_wsk_kernel(const ConvArgs a, const WsGeom g)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* lpatch = smem;
+    const int PW = g.TW + 8, PH = g.TH + 2, PWV = g.TW + 2;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwaves = blockDim.x >> 6;
+    const int p = lane & 15, kq = lane >> 4;
+    const bf16_t* __restrict__ in = static_cast<const bf16_t*>(a.in) + a.in_co;
+    const int upp = a.Cin >> 3;                                 // 16-byte pieces per pixel (10)
+    const float invPW = 1.0f / (float)PW, invTW = 1.0f / (float)g.TW;
+    const int NPB = g.TH * g.TW, nct = (NPB + 15) >> 4;
+    const int tiles_per_img = g.tiles_x * g.tiles_y;
+    const int ntiles_c = (a.Cout + 15) >> 4;
+    const int tile = min(wave, ntiles_c - 1);
+
+    bf16x8 w[NKS];
+    {
+        const bf16_t* __restrict__ wb = static_cast<const bf16_t*>(a.wgt) + lane * 8;
+#pragma unroll
+        for (int s = 0; s < NKS; ++s) w[s] = *reinterpret_cast<const bf16x8*>(wb + ((size_t)tile * a.nk + s) * 512);
+    }
+    const int ch0 = tile * 16 + kq * 4;
+    const f32x4 biasr = ch0 < a.Cout ? *reinterpret_cast<const f32x4*>(a.bias + ch0) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (unsigned)((size_t)a.M * a.out_cs * 2), 0x00020000);
+    const bool act = a.act != 0;
+    // this lane group's patch offset per k-step, two per register: group G = 4 s + kq -> tap G / 10 (taps beyond the ninth: zero weights, offset 0)
+    unsigned toff2[(NKS + 1) / 2];
+#pragma unroll
+    for (int s2 = 0; s2 < (NKS + 1) / 2; ++s2) {
+        unsigned v = 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int s = s2 * 2 + h;
+            const int G = 4 * s + kq;
+            const int tap = (G * 205) >> 11;                    // G / 10 for G < 1024
+            const int c8 = G - tap * 10;
+            const int ky = (tap * 11) >> 5, kx = tap - ky * 3;  // tap / 3 for tap < 32
+            const unsigned o = (s < NKS && tap < 9) ? (unsigned)((ky * PW + kx) * g.pitch + c8 * 16) : 0u;
+            v |= o << (16 * h);
+        }
+        toff2[s2] = v;
+    }
+    auto toff = [&](int s) -> unsigned { return (s & 1) ? toff2[s >> 1] >> 16 : toff2[s >> 1] & 0xffffu; };
+
+    const int upitch = g.pitch >> 4;
+    const int NLU = PH * PW * upitch, ndma = (NLU + 63) >> 6;
+    const float inv_upitch = 1.0f / (float)upitch;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(in), 0, (unsigned)(((size_t)a.M / (a.Ho * a.Wo) * a.H * a.W * a.in_cs - a.in_co) * 2), 0x00020000);
+    auto dma_patch = [&](int tl, unsigned char* dst) {
+        const int b = tl / tiles_per_img;
+        const int r = tl - b * tiles_per_img;
+        const int ty = r / g.tiles_x;
+        const int y0 = ty * g.TH, x0 = (r - ty * g.tiles_x) * g.TW;
+        for (int k = wave; k < ndma; k += nwaves) {
+            const int u = k * 64 + lane;
+            const int px = (int)(((float)u + 0.5f) * inv_upitch), part = u - px * upitch;
+            const int py = (int)(((float)px + 0.5f) * invPW), pxx = px - py * PW;
+            const int gy = y0 - 1 + py, gx = x0 - 1 + pxx;
+            const bool ok = part < upp && pxx < PWV && py < PH && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+            const unsigned off = ok ? (unsigned)((((b * a.H + gy) * a.W + gx) * a.in_cs) * 2 + part * 16) : 0x80000000u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)(dst + k * 1024), 16, off, 0, 0, 0);
+        }
+    };
+    if ((int)blockIdx.x < g.total_tiles) dma_patch(blockIdx.x, lpatch);
+    for (int tl = blockIdx.x; tl < g.total_tiles; tl += gridDim.x) {
+        const int b = tl / tiles_per_img;
+        const int r = tl - b * tiles_per_img;
+        const int ty = r / g.tiles_x;
+        const int y0 = ty * g.TH, x0 = (r - ty * g.tiles_x) * g.TW;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's pieces of the patch have landed (and its stores of the previous tile are out)
+        __syncthreads();
+        auto pair_setup = [&](int t0, const unsigned char* (&px)[2], int (&ob)[2]) {
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int t = min(t0 + h2, nct - 1);
+                const int q = t * 16 + p;
+                const int qc = min(q, NPB - 1);
+                const int oy = (int)(((float)qc + 0.5f) * invTW), ox = qc - oy * g.TW;
+                px[h2] = lpatch + (oy * PW + ox) * g.pitch;
+                const int gy = y0 + oy, gx = x0 + ox;
+                const bool ok = (t0 + h2 < nct) && q < NPB && gy < a.Ho && gx < a.Wo && ch0 < a.Cout && wave < ntiles_c;
+                const int m = (b * a.Ho + gy) * a.Wo + gx;
+                ob[h2] = ok ? (m * a.out_cs + a.out_co + ch0) * 2 : (int)0x80000000;
+            }
+        };
+        auto pair_mma = [&](const unsigned char* const (&px)[2], f32x4 (&acc)[2]) {
+            acc[0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            constexpr int DEPTH = 2;
+            bf16x8 xf[2][DEPTH + 1];
+#pragma unroll
+            for (int s = 0; s < DEPTH; ++s) { xf[0][s] = *reinterpret_cast<const bf16x8*>(px[0] + toff(s)); xf[1][s] = *reinterpret_cast<const bf16x8*>(px[1] + toff(s)); }
+#pragma unroll
+            for (int s = 0; s < NKS; ++s) {
+                if (s + DEPTH < NKS) {
+                    xf[0][(s + DEPTH) % (DEPTH + 1)] = *reinterpret_cast<const bf16x8*>(px[0] + toff(s + DEPTH));
+                    xf[1][(s + DEPTH) % (DEPTH + 1)] = *reinterpret_cast<const bf16x8*>(px[1] + toff(s + DEPTH));
+                }
+                acc[0] = mma_step(w[s], xf[0][s % (DEPTH + 1)], acc[0]);
+                acc[1] = mma_step(w[s], xf[1][s % (DEPTH + 1)], acc[1]);
+            }
+        };
+        auto pair_store = [&](const f32x4 (&acc)[2], const int (&ob)[2]) {
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                f32x4 o = acc[h2] + biasr;
+#pragma unroll
+                for (int r2 = 0; r2 < 4; ++r2) o[r2] = act ? silu<bf16_t>(o[r2]) : o[r2];
+                const bf16x4 wv = to_bf16x4(o);
+                typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, wv), rout, ob[h2], 0, 0);
+            }
+        };
+        {
+            const unsigned char* pxa[2];
+            int oba[2];
+            f32x4 acca[2];
+            pair_setup(0, pxa, oba);
+            pair_mma(pxa, acca);
+            for (int t0 = 2; t0 < nct; t0 += 2) {
+                const unsigned char* pxb[2];
+                int obb[2];
+                f32x4 accb[2];
+                pair_setup(t0, pxb, obb);
+                pair_store(acca, oba);                          // epilogue of the previous pair beside the MFMAs of this one
+                pair_mma(pxb, accb);
+                oba[0] = obb[0]; oba[1] = obb[1]; acca[0] = accb[0]; acca[1] = accb[1];
+            }
+            pair_store(acca, oba);
+        }
+        if (tl + (int)gridDim.x < g.total_tiles) {
+            __syncthreads();                                    // everybody is done reading the patch: the next tile's may land
+            dma_patch(tl + gridDim.x, lpatch);
+        }
+    }
+}
+
+// tile plan of the K-packed kernel: as ws_plan, for a pixel pitch of exactly cin * 2 = 160 bytes (ten 16-byte pieces, no padding).  That is the pitch
+// conv3x3_ws_kernel uses for 64 channels (128 + 32), and it is conflict-free here for the same reason: a 16-lane group of ds_read_b128 holds 8 pixels of
+// one lane group (pieces 10 p: all even slots of the 256-byte bank row) and 8 of its neighbour, whose offset is ONE piece further -- the next piece of the
+// same tap, or, where a k-step straddles two taps, piece 0 of the next pixel, which in an unpadded row is again exactly one piece on.  (First version:
+// 160 + 32 = 192 bytes = 12 pieces: 12 p mod 16 has period 4, SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.51, no faster than the LDS-tiled kernel.)
+static bool wsk_plan(int H, int W, int cin, int n, WsGeom* g)
+{
+    const int pitch = cin * 2;
+    long best = -1;
+    for (int th = 4; th <= 32; ++th)
+        for (int tw = 8; tw <= 32; ++tw) {
+            const long ph = th + 2, pw = tw + 8;
+            const long lds = (ph * pw * pitch + 1023) / 1024 * 1024;
+            if (lds > 64 * 1024) continue;
+            const int tx = (W + tw - 1) / tw, ty = (H + th - 1) / th;
+            const long tiles = (long)tx * ty * n;
+            const long rounds = (tiles + 2 * num_cus() - 1) / (2 * num_cus());
+            const long key = rounds * ((th * tw + 15) / 16 * 16 + 64) * 4096 + ph * pw;
+            if (best < 0 || key < best) { best = key; g->TH = th; g->TW = tw; g->tiles_x = tx; g->tiles_y = ty; }
+        }
+    if (best < 0) return false;
+    g->pitch = pitch; g->nchunks = 0;
+    return true;
+}
+
+// may this conv take it?  (3x3 stride 1, 80 real input channels, 80 output channels, enough pixels for the persistent grid, tiles that cover the map well)
+bool conv_wsk_ok(int cin, int cout, int n, int Ho, int Wo)
+{
+    if (cin != 80 || cout != 80) return false;
+    WsGeom g{};
+    if (!wsk_plan(Ho, Wo, cin, n, &g)) return false;
+    const double util = (double)Ho * Wo / ((double)g.tiles_x * g.tiles_y * g.TH * g.TW);
+    const char* mt = getenv("ZLY_WS_MIN_TILES");
+    return util >= 0.7 && (long)n * Ho * Wo >= (mt ? atol(mt) : 64) * 169L;
+}
+
+hipError_t launch_conv_wsk(const ConvArgs& a, hipStream_t s)
+{
+    WsGeom g{};
+    const int n = a.M / (a.Ho * a.Wo);
+    if (a.Cin != 80 || a.Cout != 80 || a.nk != 23 || a.stride != 1 || a.pad != 1 || a.in2 || a.res || a.out_f32 || a.in_cs % 8 || a.in_co % 8 || a.out_cs % 4 || a.out_co % 4 ||
+        !wsk_plan(a.Ho, a.Wo, a.Cin, n, &g)) return hipErrorInvalidValue;
+    if ((size_t)a.M * (size_t)std::max(a.in_cs, a.out_cs) * 2 >= ((size_t)1 << 31)) return hipErrorInvalidValue;        // 32-bit buffer offsets (the caller falls back)
+    g.total_tiles = g.tiles_x * g.tiles_y * n;
+    g.nwc = 5; g.nwp = 1;
+    const size_t lds = ((size_t)(g.TH + 2) * (g.TW + 8) * g.pitch + 1023) / 1024 * 1024;
+    const int gx = g.total_tiles < 2 * num_cus() ? g.total_tiles : 2 * num_cus();
+    hipLaunchKernelGGL(conv3x3_wsk_kernel<23>, dim3(gx), dim3(320), lds, s, a, g);
+    return hipGetLastError();
+}
+
 typedef void (*conv_ws_fn)(const ConvArgs, const WsGeom);
 static conv_ws_fn pick_ws(int cin, int tpw, bool res = false, bool rowt = false, int stride = 1)
 {
@@ -1165,6 +1370,10 @@ static bool ws_plan(int H, int W, int cin, int n, WsGeom* g, int stride = 1)
 
 hipError_t ws_init()
 {
+    {
+        hipError_t r = hipFuncSetAttribute((const void*)conv3x3_wsk_kernel<23>, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_MAX);
+        if (r != hipSuccess) return r;
+    }
     for (int tpw = 1; tpw <= 2; ++tpw)
         for (int res = 0; res <= 1; ++res)
             for (int rowt = 0; rowt <= 1; ++rowt) {

@@ -66,6 +66,8 @@ __device__ __forceinline__ void pair_taps(const unsigned char* __restrict__ src,
 #pragma unroll
     for (int c = 0; c < G::CT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
     const unsigned char* wl = lw + lane * G::FRAGB;
+    // C = 16 (8-byte fragments): the kx offsets as opaque registers, so that the three reads of a row are never fused into ds_read2_b64 (conv_device.h)
+    const int kxo[3] = {0, G::FRAGB == 8 ? opaque_offset(G::PITCH) : G::PITCH, G::FRAGB == 8 ? opaque_offset(2 * G::PITCH) : 2 * G::PITCH};
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
         const unsigned char* row = src + off + ky * rowb;
@@ -73,7 +75,7 @@ __device__ __forceinline__ void pair_taps(const unsigned char* __restrict__ src,
         for (int kx = 0; kx < 3; ++kx) {
 #pragma unroll
             for (int ks = 0; ks < G::KS; ++ks) {
-                const F x = *reinterpret_cast<const F*>(row + kx * G::PITCH + ks * 64);
+                const F x = *reinterpret_cast<const F*>(row + (G::FRAGB == 8 ? kxo[kx] : kx * G::PITCH) + ks * 64);
 #pragma unroll
                 for (int c = 0; c < G::CT; ++c) {
                     const F w = *reinterpret_cast<const F*>(wl + ((c * 9 + ky * 3 + kx) * G::KS + ks) * G::WTILE);

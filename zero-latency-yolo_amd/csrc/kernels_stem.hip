@@ -15,6 +15,7 @@
 //      fragment (two taps x 4 channels);
 //   4. bias + SiLU, 8-byte NHWC stores: the 4 lanes of a pixel write its 32 bytes contiguously.
 #include "zly_internal.h"
+#include "conv_device.h"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -517,6 +518,7 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 8 : NW == 12 ? 6 : 4) void stem
             wb[k % (WREG ? 9 : 1)] = *reinterpret_cast<const s16x4*>(wl + (1 * 9 + k) * 512);
         }
     }
+    const int kxo[3] = {0, opaque_offset(STEM1_PITCH), opaque_offset(2 * STEM1_PITCH)};
     auto m1_tile = [&](int t, f32x4& acc0, f32x4& acc1, int& oy, int& ox) {
         const int qc = min(t * 16 + p, NO - 1);
         oy = div_small_s(qc, invTW); ox = qc - __mul24(oy, a.TW);
@@ -526,7 +528,7 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 8 : NW == 12 ? 6 : 4) void stem
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
-                const s16x4 x = *reinterpret_cast<const s16x4*>(row0 + ((size_t)ky * RW + kx) * STEM1_PITCH);
+                const s16x4 x = *reinterpret_cast<const s16x4*>(row0 + __mul24(ky, RW * STEM1_PITCH) + kxo[kx]);      // kx offsets opaque: never ds_read2_b64, which is 2-way conflicted at this pitch (conv_device.h)
                 const s16x4 fa = WREG ? wa[(ky * 3 + kx) % (WREG ? 9 : 1)] : *reinterpret_cast<const s16x4*>(wl + (0 * 9 + ky * 3 + kx) * 512);
                 const s16x4 fb = WREG ? wb[(ky * 3 + kx) % (WREG ? 9 : 1)] : *reinterpret_cast<const s16x4*>(wl + (1 * 9 + ky * 3 + kx) * 512);
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(fa, x, acc0, 0, 0, 0);

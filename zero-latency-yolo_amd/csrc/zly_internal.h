@@ -56,6 +56,9 @@ void       conv_pick_config(int dtype, int ks, int stride, int cin, int cout_pad
                             bool plain = false,         // single source, activation dtype output: may take the weight-stationary 3x3 kernel
                             bool dual = false);         // 1x1 with the fused Upsample + Concat input, otherwise as `streamable`: may take the weight-stationary 1x1 kernel
 hipError_t conv_init();
+// the 80 -> 80 class-branch convs: weight-stationary with K packed across taps (kernels_conv.hip: conv3x3_wsk_kernel); weights tiled with cin_store = 80
+bool       conv_wsk_ok(int cin, int cout, int n, int Ho, int Wo);
+hipError_t launch_conv_wsk(const ConvArgs& a, hipStream_t s);
 int        conv_kstep(int dtype);
 
 // kernels_pair.hip -- a C2f bottleneck (two 3x3 convs, c -> c -> c, optional shortcut) as one kernel; bf16, c = 16 / 32
