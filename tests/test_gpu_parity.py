@@ -356,7 +356,7 @@ def test_production_kernels_layerwise_vs_oracle(weights_path, oracle, ref_fp32, 
                                        (416, 416, 3, {"ZLY_WS1_NO_DUAL": "1"}), (352, 288, 5, {"ZLY_WS1": "2", "ZLY_WS1_MIN_PX": "1", "ZLY_WS1_MAX_BYTES": "1"}),
                                        (352, 288, 5, {"ZLY_NO_WS_S2": "1"}), (224, 416, 4, {"ZLY_NO_WS_S2": "1"}), (352, 288, 5, {"ZLY_NO_WS_S2_C32": "1"}),
                                        (352, 288, 5, {"ZLY_WS_MAX_BYTES": "1"}), (416, 416, 3, {"ZLY_STEM1_VAR": "0"}), (352, 288, 5, {"ZLY_STEM1_VAR": "0"}),
-                                       (416, 416, 3, {"ZLY_NO_WSK": "1"}), (352, 288, 5, {"ZLY_NO_WSK": "1"}), (416, 416, 3, {"ZLY_SPPF_FUSED": "1"}), (224, 416, 4, {"ZLY_SPPF_FUSED": "1"}), (352, 288, 5, {"ZLY_SPPF_FUSED": "1"})])
+                                       (416, 416, 3, {"ZLY_WS_TPW1_MAXCT": "0"}), (352, 288, 5, {"ZLY_WS_TPW1_MAXCT": "64"}), (416, 416, 3, {"ZLY_NO_WSK": "1"}), (352, 288, 5, {"ZLY_NO_WSK": "1"}), (416, 416, 3, {"ZLY_SPPF_FUSED": "1"}), (224, 416, 4, {"ZLY_SPPF_FUSED": "1"}), (352, 288, 5, {"ZLY_SPPF_FUSED": "1"})])
 def test_throughput_kernels_on_ragged_maps(weights_path, oracle, monkeypatch, w, h, n, env):
     """conv3x3_lds_kernel, conv1x1_stream_kernel and bottleneck_pair_kernel forced onto small batches of ragged maps (88x72 ..
     11x9, 104x104 .. 13x13, 56x104 .. 7x13: partial tiles on every edge, 13-row maps, last pixel groups that are not full,
@@ -386,6 +386,8 @@ def test_throughput_kernels_on_ragged_maps(weights_path, oracle, monkeypatch, w,
         assert "conv3x3_ws_kernel<ROWT" in kn, kn
     elif not env:
         assert "conv3x3_ws_kernel<TPW" in kn and "conv3x3_ws_kernel<ROWT" not in kn, kn
+    if "ZLY_WS_TPW1_MAXCT" in env:                  # 64 -> 64 as 4 waves x one tile: never / on every tile size
+        assert ("TPW=1,4 channel tiles" in kn) == (env["ZLY_WS_TPW1_MAXCT"] != "0"), kn
     if "ZLY_C2F32_NW" in env:
         nws = [s_.split("NW=")[1].split(",")[0] for s_ in e.op_kernels(n) if s_.startswith("c2f_kernel<C=32")]
         assert nws and all(v == env["ZLY_C2F32_NW"] for v in nws), kn

@@ -2230,7 +2230,7 @@ int32_t zly_op_kernel_name(zly_engine* e, int32_t i, int32_t n, char* out, size_
         const int cin = op.in.C + (op.in2.buf >= 0 ? op.in2.C : 0);
         const ConvLaunch c = conv_launch_of(e, op, n);
         if (c.ws1) k = std::string("conv1x1_ws_kernel<") + (op.in2.buf >= 0 ? "dual-source," : "") + "NK=" + std::to_string(cin / 32) + "," + std::to_string(c.ct) + " channel tiles," + std::to_string(c.pt * 16) + " px>";
-        else if (c.ps) k = std::string("conv3x3_ws_kernel<") + (op.stride == 2 ? "S=2," : "") + (c.rowt ? "ROWT," : "") + "TPW=2," + std::to_string(c.ct) + " channel tiles>";
+        else if (c.ps) k = std::string("conv3x3_ws_kernel<") + (op.stride == 2 ? "S=2," : "") + (c.rowt ? "ROWT," : "") + (c.tpw1 ? "TPW=1," : "TPW=2,") + std::to_string(c.ct) + " channel tiles>";
         else if (c.lds) k = "conv3x3_lds_kernel<S=" + std::to_string(op.stride) + ",CT=" + std::to_string(c.ct) + ",PT=" + std::to_string(c.pt) + (c.wres ? ",wres>" : ">");
         else if (c.stream) k = "conv1x1_stream_kernel<CT=" + std::to_string(c.ct) + ",PT=" + std::to_string(c.pt) + ",NK=" + std::to_string((cin + 31) / 32) + ">";
         else k = std::string("conv_igemm_kernel<") + (op.ks == 1 ? (op.in2.buf >= 0 ? "1x1 dual-source" : "1x1") : (c.fastk ? "3x3" : "3x3 generic-K")) +

@@ -918,7 +918,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ws_kernel(const ConvArgs a, co
     const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.res ? a.res : a.out), 0,
                                                                           (unsigned)((size_t)a.M * (a.res ? a.res_cs : a.out_cs) * 2), 0x00020000);
     // this lane's first output channel: TPW = 2 -> a pair of tiles (pair-permuted rows): 8 consecutive channels; TPW = 1 -> 4 channels of tile wc
-    const int ch0 = TPW == 2 ? wc * 32 + kq * 8 : wc * 16 + kq * 4;
+    // (one tile per wave: the tile may be one of a pair-permuted pair -- 64 channels as 4 waves x 1 tile -- or a plain odd last tile: tile_channel tells)
+    const int ch0 = TPW == 2 ? wc * 32 + kq * 8 : tile_channel(wc, kq, (((a.Cout + 15) >> 4) >> 1) << 1);
     const bool act = a.act != 0;
     constexpr bool has_res = RES;                            // a template parameter: a run-time test would split the block the epilogue shares with the next pair's MFMAs
     // tap offsets of the k-steps inside the patch (wave-uniform): k-step s = tap * nchunks + chunk
@@ -1335,7 +1336,9 @@ typedef void (*conv_ws_fn)(const ConvArgs, const WsGeom);
 static conv_ws_fn pick_ws(int cin, int tpw, bool res = false, bool rowt = false, int stride = 1)
 {
     if (stride == 2) {          // the down-sampling convs with 32 / 64 input channels and an even number of output tiles; no residual
-        if (res || rowt || tpw != 2) return nullptr;
+        if (res || rowt) return nullptr;
+        if (tpw == 1) return cin == 64 ? conv3x3_ws_kernel<1, 18, false, false, 2> : nullptr;      // 64 -> 64 on small pixel tiles: 4 waves x one tile
+        if (tpw != 2) return nullptr;
         return cin == 64 ? conv3x3_ws_kernel<2, 18, false, false, 2> : cin == 32 ? conv3x3_ws_kernel<2, 9, false, false, 2> : nullptr;
     }
     if (cin != 64) return nullptr;
@@ -1382,6 +1385,10 @@ hipError_t ws_init()
             }
     for (int cin = 32; cin <= 64; cin += 32) {
         hipError_t r = hipFuncSetAttribute((const void*)pick_ws(cin, 2, false, false, 2), hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_MAX);
+        if (r != hipSuccess) return r;
+    }
+    {
+        hipError_t r = hipFuncSetAttribute((const void*)pick_ws(64, 1, false, false, 2), hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_MAX);
         if (r != hipSuccess) return r;
     }
     return hipSuccess;
@@ -1740,6 +1747,14 @@ static bool pick_ws_config(int stride, int cin, int cout_pad, int n, int Ho, int
     if (util < 0.7 || (long)n * Ho * Wo < (mt ? atol(mt) : 64) * 169L) return false;     // 64 x 169 pixels (batch 16 at 26 x 26) up: batch 16 +2.8 %, batch 32 +6 % on one engine; 256 before
     cfg->ps = 1; cfg->ct = cout_pad / 16; cfg->pt = 4; cfg->ksplit = 1; cfg->fastk = 1;
     cfg->rowt = (stride == 1 && getenv("ZLY_WS_ROWT") != nullptr && g.TW + 2 <= 16) ? 1 : 0;      // experiment: one MFMA tile per output row, kx taps by DPP shifts
+    {   // 64 -> 64 on small pixel tiles (the 26 x 26 maps: 7 x 13 tiles = 6 column tiles): 4 waves x ONE tile instead of 2 tile pairs x 2 pixel groups.  In the
+        // pair form a wave there has three column tiles = two rounds of its software pipeline (MFMAs of a pair beside the epilogue of the one before), mostly
+        // fill and drain: 6.7 k cycles for 1.7 k of MFMA issue (profiles/r03_ws_kernel_phase_stamps_v4.txt).  With one tile per wave it walks all six column
+        // tiles (three rounds) for the same MFMAs: 12.5 -> 11.3 us per launch, step +1.9 % (nine launches).  On 13 x 13 tiles (11 column tiles) the pair form
+        // wins (P3 box branch 23.3 vs 25.7 us: twice the fragment reads).  ZLY_WS_TPW1_MAXCT: tuning / tests (0 = never).
+        const char* t1 = getenv("ZLY_WS_TPW1_MAXCT");
+        cfg->tpw1 = (cin == 64 && cout_pad == 64 && (g.TH * g.TW + 15) / 16 <= (t1 ? atoi(t1) : 6)) ? 1 : 0;
+    }
     return true;
 }
 
@@ -1758,7 +1773,7 @@ static bool pick_ws1_config(int cin, int cout_pad, int M, ConvLaunch* cfg, bool 
 void conv_pick_config(int dtype, int ks, int stride, int cin, int cout_pad, int n, int Ho, int Wo, ConvLaunch* cfg, bool streamable, bool plain, bool dual)
 {
     const int M = n * Ho * Wo;
-    cfg->ks = ks; cfg->lds = 0; cfg->stream = 0; cfg->wres = 0; cfg->ps = 0; cfg->ws1 = 0; cfg->rowt = 0;
+    cfg->ks = ks; cfg->lds = 0; cfg->stream = 0; cfg->wres = 0; cfg->ps = 0; cfg->ws1 = 0; cfg->rowt = 0; cfg->tpw1 = 0;
     const bool no_stream = getenv("ZLY_NO_STREAM") != nullptr;             // tuning / tests
     // ZLY_WS1 (tuning / tests): 0 = never the weight-stationary 1x1 kernel, 1 = for the shapes the streaming kernel does not take, 2 = before it
     const char* w1 = getenv("ZLY_WS1");
@@ -1781,7 +1796,7 @@ void conv_pick_config(int dtype, int ks, int stride, int cin, int cout_pad, int 
 void conv_pick_direct(int dtype, int ks, int cin, int cout_pad, int M, ConvLaunch* cfg)
 {
     const int kstep = conv_kstep(dtype);
-    cfg->ks = ks; cfg->stream = 0; cfg->wres = 0; cfg->ps = 0; cfg->ws1 = 0; cfg->rowt = 0;
+    cfg->ks = ks; cfg->stream = 0; cfg->wres = 0; cfg->ps = 0; cfg->ws1 = 0; cfg->rowt = 0; cfg->tpw1 = 0;
     cfg->fastk = (ks == 3 && cin % kstep == 0) ? 1 : 0;
     cfg->ksplit = 1;
     const int ntiles = cout_pad / 16;
@@ -1868,6 +1883,14 @@ hipError_t launch_conv(int dtype, const ConvArgs& a, const ConvLaunch& cfg, hipS
         m.cout_pad = even * 16;
         m.Cout = a.Cout < even * 16 ? a.Cout : even * 16;
         g.nwc = even / 2; g.nwp = 4 / g.nwc;
+        if (cfg.tpw1 && ntiles == 4 && a.Cin == 64) {
+            // 64 output channels as 4 waves x ONE tile (every wave walks all column tiles of the pixel tile) instead of 2 tile pairs x 2 pixel groups: on
+            // small pixel tiles a wave of the pair form has two or three column tiles -- one or two rounds of its software pipeline, mostly fill and drain
+            g.nwc = 4; g.nwp = 1;
+            if (a.stride == 2) hipLaunchKernelGGL(pick_ws(a.Cin, 1, false, false, 2), dim3(gx), dim3(256), lds, s, a, g);
+            else               hipLaunchKernelGGL(pick_ws(a.Cin, 1, a.res != nullptr), dim3(gx), dim3(256), lds, s, a, g);
+            return hipGetLastError();
+        }
         if (a.stride == 2) {
             hipLaunchKernelGGL(pick_ws(a.Cin, 2, false, false, 2), dim3(gx), dim3(256), lds, s, m, g);
             return hipGetLastError();

@@ -40,7 +40,7 @@ struct ConvArgs {
     const void* in2;  int in2_cs, in2_co, split_c;
 };
 
-struct ConvLaunch { int ks, ct, pt, fastk, ksplit, lds, stream, wres, ps, ws1, rowt; };   // rowt: weight-stationary 3x3 kernel's row-tile form (ZLY_WS_ROWT, read when the shape is picked)
+struct ConvLaunch { int ks, ct, pt, fastk, ksplit, lds, stream, wres, ps, ws1, rowt, tpw1; };   // rowt: weight-stationary 3x3 kernel's row-tile form (ZLY_WS_ROWT, read when the shape is picked)
 struct ConvArgsMulti { ConvArgs a[6]; int n; };       // independent convs of one launch (conv_igemm_multi_kernel)
 hipError_t launch_conv_multi(const ConvArgsMulti& m, int ct, hipStream_t s);
 
