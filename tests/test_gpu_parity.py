@@ -279,7 +279,7 @@ def _assert_stem_close(g, t):
 
 
 @pytest.mark.parametrize("w,h", [(800, 600), (1920, 1080), (417, 415), (64, 48), (1, 1), (416, 416)])
-@pytest.mark.parametrize("stem1", [True, False])
+@pytest.mark.parametrize("stem1", [True, False, "persistent"])
 def test_fused_stem_kernels_vs_oracle(eng16d, weights_path, oracle, ref_bf16, monkeypatch, w, h, stem1):
     """The PRODUCTION front of the bf16 engine has its own nearest-neighbour resize map, BGR->RGB and u8 -> bf16 scaling:
     stem_model1_kernel (preprocess + model.0 + model.1, the stem map stays in LDS; kernels_stem.hip) and, when that fusion is
@@ -293,7 +293,14 @@ def test_fused_stem_kernels_vs_oracle(eng16d, weights_path, oracle, ref_bf16, mo
     assert rc == 0
     ref_bf16.forward(torch.from_numpy(pre[None]))
     t0, t1 = ref_bf16.taps["model.0"][0].numpy(), ref_bf16.taps["model.1"][0].numpy()
-    if stem1:
+    if stem1 == "persistent":
+        # ZLY_STEM1_VAR=2: workgroups walk several tiles (7 workgroups for the 104 tiles of the two-frame batch below: the tile loop crosses the frame
+        # boundary and mixes the model-sized frame's quad staging, prefetched a tile ahead, with the other frame's resize map)
+        monkeypatch.setenv("ZLY_STEM1_VAR", "2")
+        monkeypatch.setenv("ZLY_STEM1_GRID", "7")
+        e = zly.Engine(weights_path, max_batch=2, max_dets=64, warmup_runs=0, flags=zly.FLAG_DUMP_LOGITS)
+        assert "stem_model1_kernel" in e.op_kernels(1)[1]
+    elif stem1:
         e = eng16d
         assert "stem_model1_kernel" in e.op_kernels(1)[1]
     else:
@@ -308,7 +315,7 @@ def test_fused_stem_kernels_vs_oracle(eng16d, weights_path, oracle, ref_bf16, mo
     e.detect_batch([other, img], cap=8)
     _assert_stem_close(e.tap("model.0", 1), t0)
     _assert_layer_close(e.tap("model.1", 1), t1, "model.1")
-    if not stem1:
+    if stem1 is not True:
         e.close()
 
 
@@ -356,6 +363,7 @@ def test_production_kernels_layerwise_vs_oracle(weights_path, oracle, ref_fp32, 
                                        (416, 416, 3, {"ZLY_WS1_NO_DUAL": "1"}), (352, 288, 5, {"ZLY_WS1": "2", "ZLY_WS1_MIN_PX": "1", "ZLY_WS1_MAX_BYTES": "1"}),
                                        (352, 288, 5, {"ZLY_NO_WS_S2": "1"}), (224, 416, 4, {"ZLY_NO_WS_S2": "1"}), (352, 288, 5, {"ZLY_NO_WS_S2_C32": "1"}),
                                        (352, 288, 5, {"ZLY_WS_MAX_BYTES": "1"}), (416, 416, 3, {"ZLY_STEM1_VAR": "0"}), (352, 288, 5, {"ZLY_STEM1_VAR": "0"}),
+                                       (416, 416, 3, {"ZLY_STEM1_VAR": "2"}), (352, 288, 5, {"ZLY_STEM1_VAR": "2", "ZLY_STEM1_GRID": "7"}),
                                        (416, 416, 3, {"ZLY_WS_TPW1_MAXCT": "0"}), (352, 288, 5, {"ZLY_WS_TPW1_MAXCT": "64"}), (416, 416, 3, {"ZLY_NO_WSK": "1"}), (352, 288, 5, {"ZLY_NO_WSK": "1"}), (416, 416, 3, {"ZLY_SPPF_FUSED": "1"}), (224, 416, 4, {"ZLY_SPPF_FUSED": "1"}), (352, 288, 5, {"ZLY_SPPF_FUSED": "1"})])
 def test_throughput_kernels_on_ragged_maps(weights_path, oracle, monkeypatch, w, h, n, env):
     """conv3x3_lds_kernel, conv1x1_stream_kernel and bottleneck_pair_kernel forced onto small batches of ragged maps (88x72 ..
@@ -367,7 +375,8 @@ def test_throughput_kernels_on_ragged_maps(weights_path, oracle, monkeypatch, w,
     k-steps, one and two channel blocks), ZLY_WS1=0: none of them; ZLY_WS1_MAX_BYTES=1: its fall-back to the direct kernel for tensors
     beyond 32-bit byte offsets; ZLY_NO_WS_S2=1 (ZLY_NO_WS_S2_C32=1): the stride-2 convs with 32 / 64 (32) input channels on the LDS-tiled kernel instead of the weight-stationary one
     (the default runs cover that one: ragged 44x36 -> 22x18 and 28x52 -> 14x26 maps); ZLY_WS_MAX_BYTES=1: the weight-stationary 3x3 kernel's fall-back for tensors
-    beyond 32-bit byte offsets; ZLY_STEM1_VAR=0: the front kernel's round-3 staging / tap order (the default, conflict-free one runs in every other case);
+    beyond 32-bit byte offsets; ZLY_STEM1_VAR=0: the front kernel's round-3 staging / tap order (the default, conflict-free one runs in every other case), =2: its persistent form (a workgroup
+    walks several tiles, the next tile's input bytes in flight; ZLY_STEM1_GRID=7: 180 tiles on 7 workgroups);
     ZLY_SPPF_FUSED=1: the opt-in fused SPPF kernel (cv1 + three pools + cv2 in one launch; checked tap by tap like the three-launch form: model.9.cv1, model.9.cv2)."""
     import yolov8_ref
     for k, v in dict(ZLY_LDS_MIN_TILES="1", ZLY_STREAM_MIN_GROUPS="1", ZLY_PAIR_MIN_TILES="1", ZLY_WS_MIN_TILES="1", **env).items():

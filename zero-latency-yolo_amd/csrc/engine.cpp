@@ -178,7 +178,7 @@ struct zly_engine {
     std::atomic<Ingest*> ingest{nullptr};   // created by the first zly_submit (under mu), read lock-free afterwards
 
     // tuning / test switches of the environment, read ONCE at zly_create (they used to be read per launch)
-    struct Switches { bool no_c2f = false, no_det_merge = false, no_tail_split = false, no_lanes = false, nms_general = false, no_sppf = false, no_wsk = false; int stem1_nw = 0, stem1_var = 1; std::string ablate; } sw;
+    struct Switches { bool no_c2f = false, no_det_merge = false, no_tail_split = false, no_lanes = false, nms_general = false, no_sppf = false, no_wsk = false; int stem1_nw = 0, stem1_var = 1, stem1_grid = 0; std::string ablate; } sw;
 
     std::mutex mu;                    // serialises every call that touches engine / device state
     mutable std::mutex stats_mu;      // guards `stats` only, never held across a device call: zly_get_stats cannot wait on a batch
@@ -653,7 +653,7 @@ static int build_plan_device(zly_engine* e, PlanState* ps, std::string* err)
         s1.tiles_x = (W4 + s1.TW - 1) / s1.TW; s1.tiles_y = (H4 + s1.TH - 1) / s1.TH;
         s1.dump = (e->cfg.flags & ZLY_FLAG_DUMP_LOGITS) ? 1 : 0;
         s1.wgt0p = (const char*)e->d_weights + stem_w0p;
-        s1.nw = e->sw.stem1_nw; s1.var = e->sw.stem1_var;
+        s1.nw = e->sw.stem1_nw; s1.var = e->sw.stem1_var; s1.pgrid = e->sw.stem1_grid;
     }
     for (Op& op : e->ops) {
         if (op.kind != OP_HEAD) continue;
@@ -1733,6 +1733,7 @@ int32_t zly_create(const zly_config* cfg, zly_engine** out)
     e->sw.no_wsk = getenv("ZLY_NO_WSK") != nullptr;                               // tuning / tests: the class-branch convs on the LDS-tiled kernel (96-channel padding)
     e->sw.nms_general = getenv("ZLY_NMS_GENERAL") != nullptr;                     // tests / A-B: every frame on NMS's eight-wave path
     if (const char* v = getenv("ZLY_STEM1_NW")) e->sw.stem1_nw = atoi(v);           // tuning aids: waves per workgroup of the front kernel (12 / 16), ...
+    if (const char* v = getenv("ZLY_STEM1_GRID")) e->sw.stem1_grid = atoi(v);       // ... workgroups of its persistent grid ...
     if (const char* v = getenv("ZLY_STEM1_VAR")) e->sw.stem1_var = atoi(v);         // ... and 0 = round 3's staging / tap order (A/B on one box)
     std::string err;
     int rc = load_zlyw(e->weights_path.c_str(), &e->model, &err);        // host only: file parse

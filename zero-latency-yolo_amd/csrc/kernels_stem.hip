@@ -173,6 +173,9 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4s;
 #define STEM1_PITCH 40
 #define STEM1_MAXIT 8      // input pixels staged per thread (8 waves: patches up to 4096 pixels)
 
+// a value the compiler must recompute where it stands: per-lane index arithmetic of a rarely taken path is loop-invariant across a persistent workgroup's
+// tiles, and hoisted out of the tile loop it holds registers (spills) in every phase
+__device__ __forceinline__ int pin_here(int v) { asm volatile("" : "+v"(v)); return v; }
 __device__ __forceinline__ int div_small_s(int q, float inv) { return (int)(((float)q + 0.5f) * inv); }   // exact for q < 2^20, divisor < 2^10
 
 #ifdef ZLY_STEM_DIAG
@@ -197,7 +200,7 @@ const int* stem1_tap_slot() { return STEM1_TAP_SLOT; }
 template <int NW, int VAR>
 __global__ __launch_bounds__(NW * 64, NW == 16 ? 8 : NW == 12 ? 6 : 4) void stem_model1_kernel(const Stem1Args a)
 {
-    constexpr bool NEWP = VAR >= 1;
+    constexpr bool NEWP = VAR >= 1, PERS = VAR >= 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem1[];
     const int RH = 2 * a.TH + 1, RW = 2 * a.TW + 1;          // stem pixels the tile needs
     const int PH = 2 * RH + 1, PWV = 2 * RW + 1;             // input pixels those need
@@ -215,11 +218,17 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 8 : NW == 12 ? 6 : 4) void stem
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int p = lane & 15, kq = lane >> 4;
-    const int f = blockIdx.y;
-    const int ty = blockIdx.x / a.tiles_x, tx = blockIdx.x - ty * a.tiles_x;
-    const int oy1 = ty * a.TH, ox1 = tx * a.TW;              // model.1 output tile origin
-    const int sy0 = 2 * oy1 - 1, sx0 = 2 * ox1 - 1;          // stem region origin (stem output coordinates)
-    const int iy0 = 2 * sy0 - 1, ix0 = 2 * sx0 - 1;          // input patch origin (model-input pixel coordinates)
+    // VAR <= 1: one tile per workgroup, grid (tiles of a frame, frames).  VAR 2 (PERS): grid (workgroups that fit the chip), a workgroup walks the tiles
+    // b, b + gridDim.x, ... of the batch: weights / biases are fetched once per workgroup instead of once per tile, and the input bytes of the NEXT tile
+    // are requested before this tile's convolutions, so that their memory round trip is no longer part of the staging phase.
+    const int tpf = a.tiles_x * a.tiles_y;
+    const int total = tpf * a.n;
+    auto tile_origin = [&](int tile, int& f, int& oy1, int& ox1) {
+        int b;
+        if (PERS) { f = tile / tpf; b = tile - f * tpf; } else { f = blockIdx.y; b = blockIdx.x; }
+        const int ty = b / a.tiles_x, tx = b - ty * a.tiles_x;
+        oy1 = ty * a.TH; ox1 = tx * a.TW;                    // model.1 output tile origin
+    };
 
     for (int u = tid; u < 2 * 9 * 512 / 16; u += NW * 64)
         *reinterpret_cast<u32x4s*>(lw + (size_t)u * 16) = *reinterpret_cast<const u32x4s*>(static_cast<const unsigned char*>(a.w1) + (size_t)u * 16);
@@ -228,78 +237,124 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 8 : NW == 12 ? 6 : 4) void stem
     const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(wg0 + lane * 8);
     const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(wg0 + 512 + lane * 8);
 
+    // VAR >= 1: the reciprocals come from the host (IEEE divides there give the same bits; six divides per thread were ~70 of a thread's ~630 VALU instructions)
+    const float invPW = NEWP ? a.inv_pw : 1.0f / (float)PWV, invRW = NEWP ? a.inv_rw : 1.0f / (float)RW, invTW = NEWP ? a.inv_tw : 1.0f / (float)a.TW;
+
+    // Quad staging (request size == model size, the metric's configuration; VAR >= 1): the resize map is the identity and a patch row is PWV * 3
+    // contiguous bytes of the frame.  A thread takes FOUR consecutive pixels (a quad), twice: one 12-byte load, v_cvt_f32_ubyte0..3 straight off the
+    // dwords, 12 multiplies, packed converts, TWO 16-byte LDS stores.  Lanes -> quads so that the stores are conflict-free (ds_write_b128 is served in
+    // groups of 8 consecutive lanes over 32 banks = eight 16-byte slots): the 8 lanes of a group take quads 4 qb .. 4 qb + 3 of patch rows 2 rp
+    // (lanes 0-3) and 2 rp + 1 (lanes 4-7).  A quad is 32 bytes, so one row's four first halves fill slots 0, 2, 4, 6; the next row starts 16 bytes
+    // later mod 32 (row pitch = 2 mod 4 pixels) and fills 1, 3, 5, 7.  (Round 3: consecutive lanes took consecutive quads with four 8-byte stores
+    // each, whose 16-lane groups hit 8 of 32 banks: 4-way conflicts, 62 % of this kernel's SQ_LDS_BANK_CONFLICT.)
+    // The lane -> quad map does not depend on the tile (the host checks that two quads per thread cover the patch): computed once.
+    // a tile's input bytes in flight: two quads per thread, plain scalars (an indexed struct was left in scratch memory by the compiler, with a wait for the
+    // loads in front of the scratch store); mode 0: nothing to do, 1: fast quad, 2: per-pixel quad (frame border)
+    int qpy[2] = {0, 0}, qpx[2] = {0, 0};
+    bool qok[2] = {false, false};
+    if (NEWP) {
+        const int QW = (PWV + 3) >> 2;                           // quads per patch row that hold pixels
+        const int QB = (QW + 3) >> 2;                            // blocks of four quads per row
+        const int NG = ((PH + 1) >> 1) * QB;                     // 8-lane groups = (row pair, quad block)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int u = k * NW * 64 + tid;
+            const int G = u >> 3;
+            const int rp = div_small_s(G, a.inv_qb);
+            qpy[k] = 2 * rp + ((u >> 2) & 1); qpx[k] = (4 * (G - rp * QB) + (u & 3)) * 4;
+            qok[k] = G < NG && qpy[k] < PH && qpx[k] < PWV;
+        }
+    }
+    unsigned int pa0 = 0, pa1 = 0, pa2 = 0, pb0 = 0, pb1 = 0, pb2 = 0;
+    int pma = 0, pmb = 0;
+    // One quad: 12 bytes from (iy, ix clamped into the row), whatever the quad's position.  Returns 0: no quad, 3: row outside the image (zeros),
+    // 1: the window IS the quad, 16 + (ix - clamped ix + 3): the quad hangs over the left / right frame border by 1-3 pixels -- the window is then shifted
+    // by whole pixels at conversion time (zero bytes move in = the zero padding).  Round 4 up to here took such quads pixel by pixel with one byte-wise
+    // global round trip each: every row of the half of all tiles that touch the left or right border had one.
+    auto issue_quad = [&](bool ok, int py, int px, int iy0, int ix0, const FrameDesc& d, const uint8_t* src, unsigned int& r0, unsigned int& r1, unsigned int& r2) -> int {
+        if (!ok) return 0;
+        const int iy = iy0 + py, ix = ix0 + px;
+        if ((unsigned)iy >= (unsigned)a.st.th || ix >= a.st.tw || ix + 3 < 0) return 3;
+        const int ixc = min(max(ix, 0), a.st.tw - 4);
+        const uint8_t* q = src + ((size_t)iy * d.w + ixc) * 3;
+        typedef unsigned int u32x3 __attribute__((ext_vector_type(3), aligned(1)));
+        const u32x3 v = *reinterpret_cast<const u32x3*>(q);          // 12 bytes: B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3 (unaligned global access is enabled on amdhsa)
+        r0 = v[0]; r1 = v[1]; r2 = v[2];
+        return ix == ixc ? 1 : 16 + (ix - ixc + 3);
+    };
+    auto issue_quads = [&](int tile) {
+        pma = 0; pmb = 0;
+        if (!NEWP) return;
+        int f, oy1, ox1;
+        tile_origin(tile, f, oy1, ox1);
+        const int iy0 = 4 * oy1 - 3, ix0 = 4 * ox1 - 3;
+        const FrameDesc d = a.st.desc[f];
+        if (!(d.w == a.st.tw && d.h == a.st.th)) return;     // resized frame: the general path below does its own loads
+        const uint8_t* src = a.st.src + d.src_off;
+        pma = issue_quad(qok[0], qpy[0], qpx[0], iy0, ix0, d, src, pa0, pa1, pa2);
+        pmb = issue_quad(qok[1], qpy[1], qpx[1], iy0, ix0, d, src, pb0, pb1, pb2);
+    };
+
+    const f32x4 bias0 = *reinterpret_cast<const f32x4*>(a.st.bias + kq * 4);
+    const f32x4 b1lo = *reinterpret_cast<const f32x4*>(a.b1 + kq * 8), b1hi = *reinterpret_cast<const f32x4*>(a.b1 + kq * 8 + 4);
+    // model.1's weights of both channel tiles for the 9 taps: registers for the kernel's last phase (36 VGPRs) instead of 18 LDS reads per pixel tile
+    constexpr bool WREG = NW <= 8;                           // more waves per workgroup: the register budget goes to occupancy instead
+    const unsigned char* wl = lw + lane * 8;
+    s16x4 wa[WREG ? 9 : 1], wb[WREG ? 9 : 1];
+    auto load_wregs = [&]() {
+        if (WREG) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                wa[k % (WREG ? 9 : 1)] = *reinterpret_cast<const s16x4*>(wl + (0 * 9 + k) * 512);
+                wb[k % (WREG ? 9 : 1)] = *reinterpret_cast<const s16x4*>(wl + (1 * 9 + k) * 512);
+            }
+        }
+    };
+
+    int tile = PERS ? (int)blockIdx.x : (int)(blockIdx.y * tpf + blockIdx.x);
+    issue_quads(tile);
+    for (; tile < total; tile += PERS ? (int)gridDim.x : total) {
+    int f, oy1, ox1;
+    tile_origin(tile, f, oy1, ox1);
+    const int sy0 = 2 * oy1 - 1, sx0 = 2 * ox1 - 1;          // stem region origin (stem output coordinates)
+    const int iy0 = 2 * sy0 - 1, ix0 = 2 * sx0 - 1;          // input patch origin (model-input pixel coordinates)
+
     // ---- 1. input patch ------------------------------------------------------------------------------------------
     const FrameDesc d = a.st.desc[f];
     const uint8_t* src = a.st.src + d.src_off;
     const bool same = d.w == a.st.tw && d.h == a.st.th;
     const size_t frame_bytes = (size_t)d.w * d.h * 3;
-    // VAR >= 1: the reciprocals come from the host (IEEE divides there give the same bits; six divides per thread were ~70 of a thread's ~630 VALU instructions)
-    const float invPW = NEWP ? a.inv_pw : 1.0f / (float)PWV, invRW = NEWP ? a.inv_rw : 1.0f / (float)RW, invTW = NEWP ? a.inv_tw : 1.0f / (float)a.TW;
     STEMSTAMP(0);
     if (same && NEWP) {
-        // Request size == model size (the metric's configuration): the resize map is the identity and a patch row is PWV * 3 contiguous bytes of the
-        // frame.  A thread takes FOUR consecutive pixels (a quad): one 12-byte load, v_cvt_f32_ubyte0..3 straight off the dwords, 12 multiplies, packed
-        // converts, TWO 16-byte LDS stores.  Lanes -> quads so that the stores are conflict-free (ds_write_b128 is served in groups of 8 consecutive
-        // lanes over 32 banks = eight 16-byte slots): the 8 lanes of a group take quads 4 qb .. 4 qb + 3 of patch rows 2 rp (lanes 0-3) and 2 rp + 1
-        // (lanes 4-7).  A quad is 32 bytes, so one row's four first halves fill slots 0, 2, 4, 6; the next row starts 16 bytes later mod 32
-        // (row pitch = 2 mod 4 pixels) and fills 1, 3, 5, 7.  (Round 3: consecutive lanes took consecutive quads with four 8-byte stores each, whose
-        // 16-lane groups hit 8 of 32 banks: 4-way conflicts, 62 % of this kernel's SQ_LDS_BANK_CONFLICT.)
-        const int QW = (PWV + 3) >> 2;                           // quads per patch row that hold pixels
-        const int QB = (QW + 3) >> 2;                            // blocks of four quads per row
-        const int NG = ((PH + 1) >> 1) * QB;                     // 8-lane groups = (row pair, quad block)
-        for (int u0 = 0; u0 < NG * 8; u0 += NW * 64 * 2) {
-            unsigned int r0[2][3];
-            int mode[2], pyq[2], pxq[2];
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int u = u0 + k * NW * 64 + tid;
-                const int G = u >> 3;
-                mode[k] = 0;                                     // 0: nothing to do, 1: fast quad, 2: per-pixel quad
-                const int rp = div_small_s(G, a.inv_qb);
-                const int py = 2 * rp + ((u >> 2) & 1), q4 = (4 * (G - rp * QB) + (u & 3)) * 4;
-                if (G < NG && py < PH && q4 < PWV) {
-                    pyq[k] = py; pxq[k] = q4;
-                    const int iy = iy0 + py, ix = ix0 + q4;
-                    const bool row_in = (unsigned)iy < (unsigned)a.st.th;
-                    const bool fast = row_in && ix >= 0 && ix + 3 < a.st.tw && ((size_t)iy * d.w + ix) * 3 + 12 <= frame_bytes;    // the patch row has room for all four (pitch >= PWV + 3)
-                    mode[k] = fast ? 1 : 2;
-                    if (fast) {
-                        const uint8_t* q = src + ((size_t)iy * d.w + ix) * 3;
-                        typedef unsigned int u32x3 __attribute__((ext_vector_type(3), aligned(1)));
-                        const u32x3 v = *reinterpret_cast<const u32x3*>(q);          // 12 bytes: B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3 (unaligned global access is enabled on amdhsa)
-                        r0[k][0] = v[0]; r0[k][1] = v[1]; r0[k][2] = v[2];
-                    }
+        for (int k = 0; k < 2; ++k) {
+            const int mode_k = k ? pmb : pma;
+            if (mode_k == 0) continue;
+            unsigned int x0 = k ? pb0 : pa0, x1 = k ? pb1 : pa1, x2 = k ? pb2 : pa2;
+            if (mode_k == 3) { x0 = 0u; x1 = 0u; x2 = 0u; }
+            if (mode_k >= 16) {
+                const int sft = mode_k - 19;                     // pixels; > 0: the quad starts right of the window (right frame border), < 0: left of it
+                const int kb = 3 * (sft < 0 ? -sft : sft), dw = kb >> 2, b = kb & 3;      // 3 / 6 / 9 bytes: b = 3 / 2 / 1
+                if (sft > 0) {                                   // window bytes move down by kb, zeros come in on top
+                    const unsigned int z0 = dw == 0 ? x0 : dw == 1 ? x1 : x2, z1 = dw == 0 ? x1 : dw == 1 ? x2 : 0u, z2 = dw == 0 ? x2 : 0u;
+                    x0 = __builtin_amdgcn_alignbyte(z1, z0, b); x1 = __builtin_amdgcn_alignbyte(z2, z1, b); x2 = __builtin_amdgcn_alignbyte(0u, z2, b);
+                } else {                                         // up by kb, zeros come in below
+                    const unsigned int w2 = dw == 0 ? x2 : dw == 1 ? x1 : x0, w1 = dw == 0 ? x1 : dw == 1 ? x0 : 0u, w0 = dw == 0 ? x0 : 0u;
+                    x2 = __builtin_amdgcn_alignbyte(w2, w1, 4 - b); x1 = __builtin_amdgcn_alignbyte(w1, w0, 4 - b); x0 = __builtin_amdgcn_alignbyte(w0, 0u, 4 - b);
                 }
             }
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                if (mode[k] == 1) {
-                    const float kk = 1.0f / 255.0f;              // bf16(u8 * (1/255.f)) == bf16(u8 / 255.f) for all 256 values (tests/test_model_spec.py)
-                    const unsigned int x0 = r0[k][0], x1 = r0[k][1], x2 = r0[k][2];
-                    const float b0 = (float)(x0 & 0xffu) * kk, g0 = (float)((x0 >> 8) & 0xffu) * kk, rr0 = (float)((x0 >> 16) & 0xffu) * kk;
-                    const float b1 = (float)(x0 >> 24) * kk, g1 = (float)(x1 & 0xffu) * kk, rr1 = (float)((x1 >> 8) & 0xffu) * kk;
-                    const float b2 = (float)((x1 >> 16) & 0xffu) * kk, g2 = (float)(x1 >> 24) * kk, rr2 = (float)(x2 & 0xffu) * kk;
-                    const float b3 = (float)((x2 >> 8) & 0xffu) * kk, g3 = (float)((x2 >> 16) & 0xffu) * kk, rr3 = (float)(x2 >> 24) * kk;
-                    bf16x8 lo, hi;
-                    lo[0] = (bf16_t)rr0; lo[1] = (bf16_t)g0; lo[2] = (bf16_t)b0; lo[3] = (bf16_t)0.f; lo[4] = (bf16_t)rr1; lo[5] = (bf16_t)g1; lo[6] = (bf16_t)b1; lo[7] = (bf16_t)0.f;
-                    hi[0] = (bf16_t)rr2; hi[1] = (bf16_t)g2; hi[2] = (bf16_t)b2; hi[3] = (bf16_t)0.f; hi[4] = (bf16_t)rr3; hi[5] = (bf16_t)g3; hi[6] = (bf16_t)b3; hi[7] = (bf16_t)0.f;
-                    bf16x8* dst = reinterpret_cast<bf16x8*>(patch + pyq[k] * PW + pxq[k]);      // 32-byte aligned: rows are 16-byte aligned (PW even), quads 32 bytes
-                    dst[0] = lo;
-                    dst[1] = hi;
-                } else if (mode[k] == 2) {
-                    for (int j = 0; j < 4; ++j) {
-                        const int pxx = pxq[k] + j;
-                        if (pxx >= PWV) break;
-                        const int iy = iy0 + pyq[k], ix = ix0 + pxx;
-                        bf16x4 v = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
-                        if ((unsigned)iy < (unsigned)a.st.th && (unsigned)ix < (unsigned)a.st.tw) {
-                            const uint8_t* q = src + ((size_t)iy * d.w + ix) * 3;
-                            const float kk = 1.0f / 255.0f;
-                            v[0] = (bf16_t)((float)q[2] * kk); v[1] = (bf16_t)((float)q[1] * kk); v[2] = (bf16_t)((float)q[0] * kk);
-                        }
-                        patch[pyq[k] * PW + pxx] = v;
-                    }
-                }
+            {
+                const float kk = 1.0f / 255.0f;              // bf16(u8 * (1/255.f)) == bf16(u8 / 255.f) for all 256 values (tests/test_model_spec.py)
+                const float b0 = (float)(x0 & 0xffu) * kk, g0 = (float)((x0 >> 8) & 0xffu) * kk, rr0 = (float)((x0 >> 16) & 0xffu) * kk;
+                const float b1 = (float)(x0 >> 24) * kk, g1 = (float)(x1 & 0xffu) * kk, rr1 = (float)((x1 >> 8) & 0xffu) * kk;
+                const float b2 = (float)((x1 >> 16) & 0xffu) * kk, g2 = (float)(x1 >> 24) * kk, rr2 = (float)(x2 & 0xffu) * kk;
+                const float b3 = (float)((x2 >> 8) & 0xffu) * kk, g3 = (float)((x2 >> 16) & 0xffu) * kk, rr3 = (float)(x2 >> 24) * kk;
+                bf16x8 lo, hi;
+                lo[0] = (bf16_t)rr0; lo[1] = (bf16_t)g0; lo[2] = (bf16_t)b0; lo[3] = (bf16_t)0.f; lo[4] = (bf16_t)rr1; lo[5] = (bf16_t)g1; lo[6] = (bf16_t)b1; lo[7] = (bf16_t)0.f;
+                hi[0] = (bf16_t)rr2; hi[1] = (bf16_t)g2; hi[2] = (bf16_t)b2; hi[3] = (bf16_t)0.f; hi[4] = (bf16_t)rr3; hi[5] = (bf16_t)g3; hi[6] = (bf16_t)b3; hi[7] = (bf16_t)0.f;
+                bf16x8* dst = reinterpret_cast<bf16x8*>(patch + qpy[k] * PW + qpx[k]);      // 32-byte aligned: rows are 16-byte aligned (PW even), quads 32 bytes
+                dst[0] = lo;
+                dst[1] = hi;
             }
         }
     } else if (same) {
@@ -371,9 +426,10 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 8 : NW == 12 ? 6 : 4) void stem
         const float scale_w = (float)d.w / (float)a.st.tw;
         const float scale_h = (float)d.h / (float)a.st.th;
         unsigned int raw[STEM1_MAXIT];
+        const int tidg = PERS ? pin_here(tid) : tid;
     #pragma unroll
         for (int k = 0; k < STEM1_MAXIT; ++k) {
-            const int u = tid + k * NW * 64;
+            const int u = tidg + k * NW * 64;
             raw[k] = 0x80000000u;                                   // bit 31: pixel outside the model-sized image (or beyond the patch) -> zeros
             if (u < PH * PWV) {
                 const int py = div_small_s(u, invPW), px = u - py * PWV;
@@ -395,7 +451,7 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 8 : NW == 12 ? 6 : 4) void stem
         }
     #pragma unroll
         for (int k = 0; k < STEM1_MAXIT; ++k) {
-            const int u = tid + k * NW * 64;
+            const int u = tidg + k * NW * 64;
             if (u < PH * PWV) {
                 bf16x4 v = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
                 if (!(raw[k] & 0x80000000u)) {
@@ -407,6 +463,7 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 8 : NW == 12 ? 6 : 4) void stem
             }
         }
     }
+    if (PERS && tile + (int)gridDim.x < total) issue_quads(tile + (int)gridDim.x);      // in flight across both convolutions of this tile
     STEMSTAMP(1);
     __syncthreads();
     STEMSTAMP(2);
@@ -429,7 +486,6 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 8 : NW == 12 ? 6 : 4) void stem
                 toff[s][j] = ky * PW + kx;
             }
     }
-    const f32x4 bias0 = *reinterpret_cast<const f32x4*>(a.st.bias + kq * 4);
     const int NR = RH * RW, ntR = (NR + 15) >> 4;
     // One 16-pixel tile of the region: fragments -> 2 MFMAs -> bias + SiLU -> LDS map.  Lanes beyond the region's last pixel work on a copy of
     // it (same inputs, same result, same address: the store needs no guard), so the body has no branch and two tiles can be interleaved:
@@ -505,19 +561,8 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 8 : NW == 12 ? 6 : 4) void stem
     STEMSTAMP(4);
 
     // ---- 3. model.1 (3x3 s2, 16 -> 32) from the LDS map --------------------------------------------------------------------
-    f32x4 b1lo = *reinterpret_cast<const f32x4*>(a.b1 + kq * 8), b1hi = *reinterpret_cast<const f32x4*>(a.b1 + kq * 8 + 4);
     const int NO = a.TH * a.TW, ntO = (NO + 15) >> 4;
-    const unsigned char* wl = lw + lane * 8;
-    // weights of both channel tiles for the 9 taps: registers for the kernel's last phase (36 VGPRs) instead of 18 LDS reads per pixel tile
-    constexpr bool WREG = NW <= 8;                           // more waves per workgroup: the register budget goes to occupancy instead
-    s16x4 wa[WREG ? 9 : 1], wb[WREG ? 9 : 1];
-    if (WREG) {
-#pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            wa[k % (WREG ? 9 : 1)] = *reinterpret_cast<const s16x4*>(wl + (0 * 9 + k) * 512);
-            wb[k % (WREG ? 9 : 1)] = *reinterpret_cast<const s16x4*>(wl + (1 * 9 + k) * 512);
-        }
-    }
+    load_wregs();                                            // per tile (LDS reads): held across the loop they cost 36 VGPRs of every phase's budget
     const int kxo[3] = {0, opaque_offset(STEM1_PITCH), opaque_offset(2 * STEM1_PITCH)};
     auto m1_tile = [&](int t, f32x4& acc0, f32x4& acc1, int& oy, int& ox) {
         const int qc = min(t * 16 + p, NO - 1);
@@ -566,6 +611,8 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 8 : NW == 12 ? 6 : 4) void stem
         m1_finish(t3, a0, a1, oyA, oxA);
     }
     STEMSTAMP(5);
+    if (!PERS) break;
+    }   // tiles of this workgroup
 #ifdef ZLY_STEM_DIAG
     if (lane == 0 && g_stem_diag) {
         unsigned long long* o = g_stem_diag + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * NW + wave) * 8;
@@ -597,34 +644,51 @@ void stem1_plan(int H1, int W1, int* th, int* tw)
 typedef void (*stem1_fn)(const Stem1Args);
 static stem1_fn pick_stem1(int nw, int var)
 {
-    if (var >= 1) return nw == 12 ? stem_model1_kernel<12, 1> : nw == 16 ? stem_model1_kernel<16, 1> : stem_model1_kernel<STEM1_NW, 1>;
+    if (var >= 2) return nw == 12 ? stem_model1_kernel<12, 2> : nw == 16 ? stem_model1_kernel<16, 2> : stem_model1_kernel<STEM1_NW, 2>;
+    if (var == 1) return nw == 12 ? stem_model1_kernel<12, 1> : nw == 16 ? stem_model1_kernel<16, 1> : stem_model1_kernel<STEM1_NW, 1>;
     return nw == 12 ? stem_model1_kernel<12, 0> : nw == 16 ? stem_model1_kernel<16, 0> : stem_model1_kernel<STEM1_NW, 0>;
 }
 
+static int g_stem1_cus = 256;
 hipError_t stem1_init()
 {
-    for (int var = 0; var <= 1; ++var)
+    for (int var = 0; var <= 2; ++var)
         for (int nw : {STEM1_NW, 12, 16}) {
             hipError_t r = hipFuncSetAttribute((const void*)pick_stem1(nw, var), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (r != hipSuccess) return r;
         }
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) g_stem1_cus = cus;
     return hipSuccess;
 }
 
-// a.nw: waves per workgroup (8; 12 / 16 = tuning aid ZLY_STEM1_NW), a.var: 1 = conflict-free staging and tap order (default), 0 = round 3's (ZLY_STEM1_VAR=0);
-// both are read by the engine once per zly_create, not here (a process-static switch cannot be toggled by a test)
+// a.nw: waves per workgroup (8; 12 / 16 = tuning aid ZLY_STEM1_NW); a.var: 2 = persistent workgroups with the next tile's input bytes in flight (default),
+// 1 = one tile per workgroup, 0 = round 3's staging / tap order as well (ZLY_STEM1_VAR, A/B on one box).  Both are read by the engine once per
+// zly_create, not here (a process-static switch cannot be toggled by a test)
 hipError_t launch_stem_model1(const Stem1Args& a0, int n, hipStream_t s)
 {
     Stem1Args a = a0;
     if (a.st.Cout != 16 || a.TH < 1 || a.TW < 1 || a.out1_cs % 8 || a.out1_co % 8) return hipErrorInvalidValue;
     if (a.H1 * 2 != a.st.Ho || a.W1 * 2 != a.st.Wo) return hipErrorInvalidValue;      // even stem map: model.1 output = half of it
-    const int nw = (a.nw == 12 || a.nw == 16) ? a.nw : STEM1_NW, var = a.var >= 1 ? 1 : 0;
+    const int nw = (a.nw == 12 || a.nw == 16) ? a.nw : STEM1_NW, var = a.var >= 2 ? 2 : a.var == 1 ? 1 : 0;
     if (var >= 1 && !a.wgt0p) return hipErrorInvalidValue;
     const size_t lds = stem1_lds_bytes(a.TH, a.TW, var);
     if (lds > 160 * 1024 || (4 * a.TH + 3) * (4 * a.TW + 3) > STEM1_MAXIT * STEM1_NW * 64) return hipErrorInvalidValue;
-    const int pwv = 4 * a.TW + 3, qb = ((pwv + 3) / 4 + 3) / 4;
+    const int ph = 4 * a.TH + 3, pwv = 4 * a.TW + 3, qb = ((pwv + 3) / 4 + 3) / 4;
+    if (var >= 1 && ((ph + 1) / 2) * qb * 8 > nw * 64 * 2) return hipErrorInvalidValue;    // the quad staging takes two quads per thread
     a.inv_pw = 1.0f / (float)pwv; a.inv_rw = 1.0f / (float)(2 * a.TW + 1); a.inv_tw = 1.0f / (float)a.TW; a.inv_qb = 1.0f / (float)qb;
-    hipLaunchKernelGGL(pick_stem1(nw, var), dim3(a.tiles_x * a.tiles_y, n), dim3(nw * 64), lds, s, a);
+    a.n = n;
+    const long long total = (long long)a.tiles_x * a.tiles_y * n;
+    if (total > 0x7fffffff) return hipErrorInvalidValue;
+    if (var >= 2) {
+        // as many workgroups as stay resident (LDS: 160 KB per CU); with fewer tiles than that, one tile each
+        long long wgs = (long long)g_stem1_cus * (long long)((160 * 1024) / lds < 1 ? 1 : (160 * 1024) / lds);
+        if (a.pgrid > 0) wgs = a.pgrid;                                                            // tuning aid ZLY_STEM1_GRID (read by the engine per zly_create)
+        if (wgs > total) wgs = total;
+        hipLaunchKernelGGL(pick_stem1(nw, var), dim3((unsigned)wgs), dim3(nw * 64), lds, s, a);
+    } else {
+        hipLaunchKernelGGL(pick_stem1(nw, var), dim3(a.tiles_x * a.tiles_y, n), dim3(nw * 64), lds, s, a);
+    }
     return hipGetLastError();
 }
 

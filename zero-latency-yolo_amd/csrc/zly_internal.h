@@ -124,7 +124,9 @@ struct Stem1Args {
     int H1, W1;                               // model.1 output map
     int TH, TW, tiles_x, tiles_y;
     int dump;
-    int nw, var;                              // waves per workgroup (0 = default), kernel variant (1 = conflict-free staging / tap order, 0 = round 3's)
+    int nw, var;                              // waves per workgroup (0 = default), kernel variant (2 = persistent workgroups + input prefetch, 1 = one tile per workgroup, 0 = round 3's staging / tap order)
+    int n;                                    // frames (set by launch_stem_model1)
+    int pgrid;                                // var 2: workgroups of the persistent grid (0 = as many as stay resident)
     // set by launch_stem_model1 (host IEEE divides: the kernel used to spend six fp32 divides per thread on them)
     float inv_pw, inv_rw, inv_tw, inv_qb;     // 1 / patch row pitch, 1 / region width, 1 / tile width, 1 / quad blocks per patch row
     const void* wgt0p;                        // stem weights in the tap order of the conflict-free fragment reads (kernels_stem.hip: STEM1_TAP_SLOT)

@@ -2,7 +2,7 @@
 // (never part of libzly.so).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Izero-latency-yolo_amd/csrc -DZLY_STEM_DIAG=1 zero-latency-yolo_amd/tools/stem_bench.hip \
 //         -o zero-latency-yolo_amd/_build/stem_bench && ./zero-latency-yolo_amd/_build/stem_bench
-// YOLOv8n at 416 x 416, batch 64 (and 1): per variant (0 = round 3's staging / tap order, 1 = conflict-free) and waves per workgroup the launch time and
+// YOLOv8n at 416 x 416, batch 64 (and 1): per variant (0 = round 3's staging / tap order, 1 = conflict-free, 2 = persistent workgroups with the next tile's input in flight) and waves per workgroup the launch time and
 // the per-wave cycle sums of: prologue | patch staging (loads, convert, LDS stores) | barrier | stem conv -> LDS map | barrier | model.1 -> HBM.
 // Random weights: the timing does not depend on the values (the parity tests check them).  Read SHARES, not the stamped build's length.
 #include "../csrc/kernels_stem.hip"
@@ -19,7 +19,7 @@ static void* dalloc_bf16(size_t elems, unsigned seed)
     return d;
 }
 
-static void run(int n, int var, int nw, int th, int tw)
+static void run(int n, int var, int nw, int th, int tw, int pgrid = 0)
 {
     const int W = 416, H = 416;
     std::vector<uint8_t> hf((size_t)n * W * H * 3);
@@ -36,7 +36,7 @@ static void run(int n, int var, int nw, int th, int tw)
     a.w1 = dalloc_bf16(2 * 9 * 256, 2); a.b1 = bias;
     void* out1; (void)hipMalloc(&out1, (size_t)n * 104 * 104 * 32 * 2); a.out1 = out1; a.out1_cs = 32;
     a.H1 = 104; a.W1 = 104; a.TH = th; a.TW = tw; a.tiles_x = (104 + tw - 1) / tw; a.tiles_y = (104 + th - 1) / th;
-    a.wgt0p = a.st.wgt; a.nw = nw; a.var = var;
+    a.wgt0p = a.st.wgt; a.nw = nw; a.var = var; a.pgrid = pgrid;
     const size_t nwaves = (size_t)a.tiles_x * a.tiles_y * n * nw;
     unsigned long long* ddbg; (void)hipMalloc((void**)&ddbg, nwaves * 64); (void)hipMemset(ddbg, 0, nwaves * 64);
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stem_diag), &ddbg, sizeof ddbg);
@@ -53,19 +53,21 @@ static void run(int n, int var, int nw, int th, int tw)
     std::vector<unsigned long long> h(nwaves * 8);
     (void)hipMemcpy(h.data(), ddbg, nwaves * 64, hipMemcpyDeviceToHost);
     double s[8] = {0}; for (size_t w = 0; w < nwaves; ++w) for (int k = 0; k < 7; ++k) s[k] += (double)h[w * 8 + k];
-    printf("batch %2d var %d, %2d waves, tile %dx%d (%d workgroups): %6.1f us best of 20 | cycles per wave (mean): prologue %.0f | staging %.0f | barrier %.0f | stem conv %.0f | barrier %.0f | model.1 %.0f | wave total %.0f\n",
-           n, var, nw, th, tw, a.tiles_x * a.tiles_y * n, best * 1e3, s[0] / nwaves, s[1] / nwaves, s[2] / nwaves, s[3] / nwaves, s[4] / nwaves, s[5] / nwaves, s[6] / nwaves);
+    printf("batch %2d var %d grid %4d, %2d waves, tile %dx%d (%d tiles): %6.1f us best of 20 | cycles per wave (mean): prologue %.0f | staging %.0f | barrier %.0f | stem conv %.0f | barrier %.0f | model.1 %.0f | wave total %.0f\n",
+           n, var, pgrid, nw, th, tw, a.tiles_x * a.tiles_y * n, best * 1e3, s[0] / nwaves, s[1] / nwaves, s[2] / nwaves, s[3] / nwaves, s[4] / nwaves, s[5] / nwaves, s[6] / nwaves);
     (void)hipFree(dsrc); (void)hipFree(ddesc); (void)hipFree(bias); (void)hipFree(out0); (void)hipFree(out1); (void)hipFree(ddbg);
     (void)hipFree(const_cast<void*>(a.st.wgt)); (void)hipFree(const_cast<void*>(a.w1));
 }
 
 int main()
 {
-    for (int var = 0; var <= 1; ++var) {
+    // cycles are sums over a wave's tiles divided by ALL tiles x waves: per tile and wave in every variant (var 2: a workgroup walks several tiles)
+    for (int var = 0; var <= 2; ++var) {
         run(64, var, 8, 8, 26);
         run(64, var, 16, 8, 26);
         run(64, var, 8, 4, 26);
         run(1, var, 8, 8, 26);
     }
+    for (int g : {256, 416, 476, 512, 555, 666, 768, 832}) run(64, 2, 8, 8, 26, g);
     return 0;
 }
