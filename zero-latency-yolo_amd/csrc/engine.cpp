@@ -759,7 +759,7 @@ static const ConvLaunch& conv_launch_of(zly_engine* e, const Op& op, int n)
         ConvLaunch c;
         conv_pick_config(e->dtype, op.ks, op.stride, cin, op.cout_pad, n, ob.H, ob.W, &c,
                          op.in2.buf < 0 && op.res.buf < 0 && op.act && !op.out_f32 && op.cout % 32 == 0,
-                         op.in2.buf < 0 && !op.out_f32,
+                         op.in2.buf < 0 && !op.out_f32 && op.act,
                          op.in2.buf >= 0 && op.ks == 1 && op.res.buf < 0 && op.act && !op.out_f32 && op.cout % 32 == 0 && op.cout_pad == op.cout);
         it = mop.launch_cache.emplace(n, c).first;
     }
@@ -786,7 +786,7 @@ static int detect_merge_role(const zly_engine* e, int i)
 // the 80 -> 80 class-branch conv on the K-packed weight-stationary kernel at this batch size?  (decided once per op and batch size)
 static bool wsk_active(zly_engine* e, const Op& op, int n)
 {
-    if (!op.wsk_w || e->sw.no_wsk || e->dtype != ZLY_DTYPE_BF16) return false;
+    if (!op.wsk_w || e->sw.no_wsk || e->dtype != ZLY_DTYPE_BF16 || !op.act) return false;
     Op& mop = const_cast<Op&>(op);
     auto it = mop.wsk_cache.find(n);
     if (it == mop.wsk_cache.end()) {

@@ -920,7 +920,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ws_kernel(const ConvArgs a, co
     // this lane's first output channel: TPW = 2 -> a pair of tiles (pair-permuted rows): 8 consecutive channels; TPW = 1 -> 4 channels of tile wc
     // (one tile per wave: the tile may be one of a pair-permuted pair -- 64 channels as 4 waves x 1 tile -- or a plain odd last tile: tile_channel tells)
     const int ch0 = TPW == 2 ? wc * 32 + kq * 8 : tile_channel(wc, kq, (((a.Cout + 15) >> 4) >> 1) << 1);
-    const bool act = a.act != 0;
     constexpr bool has_res = RES;                            // a template parameter: a run-time test would split the block the epilogue shares with the next pair's MFMAs
     // tap offsets of the k-steps inside the patch (wave-uniform): k-step s = tap * nchunks + chunk
     int toff[NKS];
@@ -1066,7 +1065,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ws_kernel(const ConvArgs a, co
                 for (int c = 0; c < TPW; ++c) {
                     o[c] = acc[h2][c] + biasr[c];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) o[c][r] = act ? silu<bf16_t>(o[c][r]) : o[c][r];
+                    for (int r = 0; r < 4; ++r) o[c][r] = silu<bf16_t>(o[c][r]);      // always SiLU here: launch_conv sends a conv without activation elsewhere (a run-time select cost one v_cndmask per value: 16 per pair)
                 }
                 if (TPW == 2) {
                     f32x4 lo = o[0], hi = o[TPW - 1];
@@ -1169,7 +1168,6 @@ __global__ __launch_bounds__(320, 3) void conv3x3_wsk_kernel(const ConvArgs a, c
     const int ch0 = tile * 16 + kq * 4;
     const f32x4 biasr = ch0 < a.Cout ? *reinterpret_cast<const f32x4*>(a.bias + ch0) : f32x4{0.f, 0.f, 0.f, 0.f};
     const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (unsigned)((size_t)a.M * a.out_cs * 2), 0x00020000);
-    const bool act = a.act != 0;
     // this lane group's patch offset per k-step, two per register: group G = 4 s + kq -> tap G / 10 (taps beyond the ninth: zero weights, offset 0)
     unsigned toff2[(NKS + 1) / 2];
 #pragma unroll
@@ -1251,7 +1249,7 @@ __global__ __launch_bounds__(320, 3) void conv3x3_wsk_kernel(const ConvArgs a, c
             for (int h2 = 0; h2 < 2; ++h2) {
                 f32x4 o = acc[h2] + biasr;
 #pragma unroll
-                for (int r2 = 0; r2 < 4; ++r2) o[r2] = act ? silu<bf16_t>(o[r2]) : o[r2];
+                for (int r2 = 0; r2 < 4; ++r2) o[r2] = silu<bf16_t>(o[r2]);       // launch_conv_wsk refuses a conv without activation
                 const bf16x4 wv = to_bf16x4(o);
                 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, wv), rout, ob[h2], 0, 0);
@@ -1321,7 +1319,7 @@ hipError_t launch_conv_wsk(const ConvArgs& a, hipStream_t s)
 {
     WsGeom g{};
     const int n = a.M / (a.Ho * a.Wo);
-    if (a.Cin != 80 || a.Cout != 80 || a.nk != 23 || a.stride != 1 || a.pad != 1 || a.in2 || a.res || a.out_f32 || a.in_cs % 8 || a.in_co % 8 || a.out_cs % 4 || a.out_co % 4 ||
+    if (a.Cin != 80 || a.Cout != 80 || a.nk != 23 || a.stride != 1 || a.pad != 1 || a.in2 || a.res || a.out_f32 || !a.act || a.in_cs % 8 || a.in_co % 8 || a.out_cs % 4 || a.out_co % 4 ||
         !wsk_plan(a.Ho, a.Wo, a.Cin, n, &g)) return hipErrorInvalidValue;
     if ((size_t)a.M * (size_t)std::max(a.in_cs, a.out_cs) * 2 >= ((size_t)1 << 31)) return hipErrorInvalidValue;        // 32-bit buffer offsets (the caller falls back)
     g.total_tiles = g.tiles_x * g.tiles_y * n;
@@ -1858,7 +1856,7 @@ hipError_t launch_conv(int dtype, const ConvArgs& a, const ConvLaunch& cfg, hipS
     if (cfg.ps) {                                                  // weight-stationary 3x3 kernel
         WsGeom g{};
         const int ntiles = a.cout_pad / 16, even = ntiles / 2 * 2;
-        if (dtype != ZLY_DTYPE_BF16 || !pick_ws(a.Cin, 2, false, false, a.stride) || a.pad != 1 || a.in2 || a.out_f32 || a.nk != 9 * a.Cin / 32 ||
+        if (dtype != ZLY_DTYPE_BF16 || !pick_ws(a.Cin, 2, false, false, a.stride) || a.pad != 1 || a.in2 || a.out_f32 || !a.act || a.nk != 9 * a.Cin / 32 ||
             a.in_cs % 8 || a.in_co % 8 || (even != 2 && even != 4 && even != 8) || !ws_plan(a.Ho, a.Wo, a.Cin, a.M / (a.Ho * a.Wo), &g, a.stride)) return hipErrorInvalidValue;
         if (a.stride == 2 && (a.res || ntiles != even)) return hipErrorInvalidValue;
         // 32-bit byte offsets into the buffer resources (and 0x80000000 as the out-of-range sentinel): a tensor of 2 GiB or more takes the LDS-tiled /
