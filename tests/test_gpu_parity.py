@@ -364,6 +364,7 @@ def test_production_kernels_layerwise_vs_oracle(weights_path, oracle, ref_fp32, 
                                        (352, 288, 5, {"ZLY_NO_WS_S2": "1"}), (224, 416, 4, {"ZLY_NO_WS_S2": "1"}), (352, 288, 5, {"ZLY_NO_WS_S2_C32": "1"}),
                                        (352, 288, 5, {"ZLY_WS_MAX_BYTES": "1"}), (416, 416, 3, {"ZLY_STEM1_VAR": "0"}), (352, 288, 5, {"ZLY_STEM1_VAR": "0"}),
                                        (416, 416, 3, {"ZLY_STEM1_VAR": "2"}), (352, 288, 5, {"ZLY_STEM1_VAR": "2", "ZLY_STEM1_GRID": "7"}),
+                                       (416, 416, 3, {"ZLY_SPPF_POOL_LDS": "1"}), (352, 288, 5, {"ZLY_SPPF_POOL_LDS": "1"}),
                                        (416, 416, 3, {"ZLY_WS_TPW1_MAXCT": "0"}), (352, 288, 5, {"ZLY_WS_TPW1_MAXCT": "64"}), (416, 416, 3, {"ZLY_NO_WSK": "1"}), (352, 288, 5, {"ZLY_NO_WSK": "1"}), (416, 416, 3, {"ZLY_SPPF_FUSED": "1"}), (224, 416, 4, {"ZLY_SPPF_FUSED": "1"}), (352, 288, 5, {"ZLY_SPPF_FUSED": "1"})])
 def test_throughput_kernels_on_ragged_maps(weights_path, oracle, monkeypatch, w, h, n, env):
     """conv3x3_lds_kernel, conv1x1_stream_kernel and bottleneck_pair_kernel forced onto small batches of ragged maps (88x72 ..
@@ -377,7 +378,8 @@ def test_throughput_kernels_on_ragged_maps(weights_path, oracle, monkeypatch, w,
     (the default runs cover that one: ragged 44x36 -> 22x18 and 28x52 -> 14x26 maps); ZLY_WS_MAX_BYTES=1: the weight-stationary 3x3 kernel's fall-back for tensors
     beyond 32-bit byte offsets; ZLY_STEM1_VAR=0: the front kernel's round-3 staging / tap order (the default, conflict-free one runs in every other case), =2: its persistent form (a workgroup
     walks several tiles, the next tile's input bytes in flight; ZLY_STEM1_GRID=7: 180 tiles on 7 workgroups);
-    ZLY_SPPF_FUSED=1: the opt-in fused SPPF kernel (cv1 + three pools + cv2 in one launch; checked tap by tap like the three-launch form: model.9.cv1, model.9.cv2)."""
+    ZLY_SPPF_FUSED=1: the opt-in fused SPPF kernel (cv1 + three pools + cv2 in one launch; checked tap by tap like the three-launch form: model.9.cv1, model.9.cv2);
+    ZLY_SPPF_POOL_LDS=1: SPPF's pools on the six-pass LDS kernel (the default on these 13 x 13 / 11 x 9 / 7 x 13 maps is sppf_pool16_kernel: DPP row windows, one barrier)."""
     import yolov8_ref
     for k, v in dict(ZLY_LDS_MIN_TILES="1", ZLY_STREAM_MIN_GROUPS="1", ZLY_PAIR_MIN_TILES="1", ZLY_WS_MIN_TILES="1", **env).items():
         monkeypatch.setenv(k, v)
@@ -410,7 +412,9 @@ def test_throughput_kernels_on_ragged_maps(weights_path, oracle, monkeypatch, w,
     assert ("conv3x3_wsk_kernel" in kn) == ("ZLY_NO_WSK" not in env and n > 4), kn        # batch <= 4: the Detect convs run as merged launches
     # SPPF: cv1 | pool | cv2 launches by default; ZLY_SPPF_FUSED=1: one launch (kernels_sppf.hip: 13 x 13, 7 x 13 and 11 x 9 maps here, split 4 ways by output channels)
     assert ("sppf_fused_kernel" in kn) == ("ZLY_SPPF_FUSED" in env), kn
-    assert ("sppf_pool_kernel" in kn) == ("ZLY_SPPF_FUSED" not in env), kn
+    assert ("sppf_pool" in kn) == ("ZLY_SPPF_FUSED" not in env), kn
+    if "ZLY_SPPF_FUSED" not in env:                 # maps of <= 16 x 16 pixels: the one-barrier kernel (DPP row windows) unless switched back to the six-pass one
+        assert ("sppf_pool16_kernel" in kn) == ("ZLY_SPPF_POOL_LDS" not in env) and ("sppf_pool_kernel" in kn) == ("ZLY_SPPF_POOL_LDS" in env), kn
     got = e.forward(x)
     checked = _check_taps(e, ref, range(n), skip_ok=(".m.0.cv1", ".m.1.cv1"))
     assert len(checked) >= 59, checked
@@ -423,6 +427,26 @@ def test_throughput_kernels_on_ragged_maps(weights_path, oracle, monkeypatch, w,
             _assert_layer_close(e.tap(name, i), ref.taps[name][i].numpy(), f"{name}[{i}] after detect")
     assert len(res) == n
     e.close()
+
+
+@pytest.mark.parametrize("w,h", [(416, 416), (352, 288), (224, 416), (512, 512)])
+def test_sppf_pool_kernels_same_bits(weights_path, monkeypatch, w, h):
+    """SPPF's three chained 5x5 max pools: the one-barrier kernel of small maps (sppf_pool16_kernel: v_pk_max_i16 in a sortable domain, row windows by
+    DPP, column windows of radius 2 / 4 / 6 read directly with clamped rows) against the six-pass fp32 LDS kernel on the same engine otherwise.
+    max is a selection: model.9.cv2 -- the conv over [y | p1 | p2 | p3] -- and the detections must come out bit for bit (13 x 13, 11 x 9, 7 x 13 and
+    16 x 16 maps: partial DPP rows, non-square maps, the largest map the kernel takes)."""
+    frames = zm.synth_frames(3, w, h, seed=77, rects=False)
+    outs = []
+    for six in (False, True):
+        if six: monkeypatch.setenv("ZLY_SPPF_POOL_LDS", "1")
+        e = zly.Engine(weights_path, model_w=w, model_h=h, max_batch=3, max_dets=64, warmup_runs=0, flags=zly.FLAG_DUMP_LOGITS)
+        assert ("sppf_pool16_kernel" in " ".join(e.op_kernels(3))) == (not six)
+        res = e.detect_batch(list(frames), cap=64)
+        outs.append(([e.tap("model.9.cv2", i) for i in range(3)], res))
+        e.close()
+    for i in range(3):
+        assert np.array_equal(outs[0][0][i], outs[1][0][i])
+        assert outs[0][1][i][1] == outs[1][1][i][1] and det_fields_equal(outs[0][1][i][0], outs[1][1][i][0])
 
 
 def test_forward_bf16_vs_fp32_oracle(eng16, oracle, ref_fp32):

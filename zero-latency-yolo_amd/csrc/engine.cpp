@@ -178,7 +178,7 @@ struct zly_engine {
     std::atomic<Ingest*> ingest{nullptr};   // created by the first zly_submit (under mu), read lock-free afterwards
 
     // tuning / test switches of the environment, read ONCE at zly_create (they used to be read per launch)
-    struct Switches { bool no_c2f = false, no_det_merge = false, no_tail_split = false, no_lanes = false, nms_general = false, no_sppf = false, no_wsk = false; int stem1_nw = 0, stem1_var = 1, stem1_grid = 0; std::string ablate; } sw;
+    struct Switches { bool no_c2f = false, no_det_merge = false, no_tail_split = false, no_lanes = false, nms_general = false, no_sppf = false, no_wsk = false, pool_six_pass = false; int stem1_nw = 0, stem1_var = 1, stem1_grid = 0; std::string ablate; } sw;
 
     std::mutex mu;                    // serialises every call that touches engine / device state
     mutable std::mutex stats_mu;      // guards `stats` only, never held across a device call: zly_get_stats cannot wait on a batch
@@ -969,7 +969,7 @@ static hipError_t run_op(zly_engine* e, const Op& op, int n, const uint8_t* d_sr
     case OP_SPPF: {
         if (sppf_active(e)) return hipSuccess;                       // inside the fused SPPF kernel
         const Buffer& b = e->bufs[(size_t)op.in.buf];
-        return launch_sppf_pool(e->dtype, b.ptr, b.C, op.c, n, b.H, b.W, s);
+        return launch_sppf_pool(e->dtype, b.ptr, b.C, op.c, n, b.H, b.W, s, e->sw.pool_six_pass ? 1 : 0);
     }
     case OP_HEAD: {
         HeadArgs h = op.head;
@@ -1730,6 +1730,7 @@ int32_t zly_create(const zly_config* cfg, zly_engine** out)
     e->sw.no_tail_split = getenv("ZLY_NO_TAIL_SPLIT") != nullptr;
     e->sw.no_lanes = getenv("ZLY_NO_LANES") != nullptr || getenv("ZLY_CU_PART") != nullptr;
     e->sw.no_sppf = getenv("ZLY_SPPF_FUSED") == nullptr;                         // the fused SPPF kernel is OPT-IN (ZLY_SPPF_FUSED=1): parity-green, 36 -> ~24 us in isolation at batch 64, but the step gets 0.5 % slower
+    e->sw.pool_six_pass = getenv("ZLY_SPPF_POOL_LDS") != nullptr;                 // tuning / tests: SPPF's pools on the six-pass LDS kernel also on small maps
     e->sw.no_wsk = getenv("ZLY_NO_WSK") != nullptr;                               // tuning / tests: the class-branch convs on the LDS-tiled kernel (96-channel padding)
     e->sw.nms_general = getenv("ZLY_NMS_GENERAL") != nullptr;                     // tests / A-B: every frame on NMS's eight-wave path
     if (const char* v = getenv("ZLY_STEM1_NW")) e->sw.stem1_nw = atoi(v);           // tuning aids: waves per workgroup of the front kernel (12 / 16), ...
@@ -2202,7 +2203,12 @@ int32_t zly_op_kernel_name(zly_engine* e, int32_t i, int32_t n, char* out, size_
     std::string k;
     switch (op.kind) {
     case OP_PREPROCESS: k = e->stem_fused ? "(fused into stem_fused_kernel)" : "preprocess_kernel"; break;
-    case OP_SPPF: k = sppf_active(e) ? "(fused into the SPPF kernel at model.9.cv1)" : "sppf_pool_kernel"; break;
+    case OP_SPPF: {
+        const Buffer& pb = e->bufs[(size_t)op.in.buf];
+        k = sppf_active(e) ? "(fused into the SPPF kernel at model.9.cv1)"
+          : (e->dtype == ZLY_DTYPE_BF16 && pb.H <= 16 && pb.W <= 16 && !e->sw.pool_six_pass && n <= 16) ? "sppf_pool16_kernel<DPP row windows, one barrier>" : "sppf_pool_kernel";
+        break;
+    }
     case OP_HEAD: k = op_is_noop(e, op, n) ? "(covered by the last tail launch)" : "head_fused_kernel"; break;
     case OP_NMS: k = "nms_kernel"; break;
     case OP_CONV: {

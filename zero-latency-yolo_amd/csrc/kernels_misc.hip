@@ -160,8 +160,87 @@ __global__ __launch_bounds__(256) void sppf_pool_kernel(T* __restrict__ buf, int
     }
 }
 
-hipError_t launch_sppf_pool(int dtype, void* buf, int cs, int c, int n, int H, int W, hipStream_t s)
+// ------------------------------------------------------------------------------------------------
+// The same three pools for maps of at most 16 x 16 pixels in bf16 (13 x 13 at 416 x 416: the headline), round 4.  sppf_pool_kernel above runs six
+// LDS passes separated by workgroup barriers on fp32 records (13.4 us per launch at batch 64 for 11 MB of traffic; an ablated step is ~20 us shorter).
+// Here: pool_k = (2k+1) x (2k+1) window of y with k = 2, 4, 6 = column window of radius k over the ROW window of radius k, and a row window of radius
+// k + 2 is the radius-2 row window of the radius-k one.  A workgroup is 16 rows x 16 lanes = one frame's map for 8 channels, a thread = one pixel
+// (16 bytes = 4 dwords of bf16 pairs):
+//   * values go to the sortable-int16 domain (T(x) = x ^ ((x >> 15) & 0x7fff) per half-word, an involution): v_pk_max_i16, two channels per instruction,
+//     exact -- max is a selection, the same bits come out as from the fp32 compare;
+//   * the three ROW windows are built in registers with DPP row shifts (a DPP row IS a map row; lanes shifted in from outside the row, and the lanes /
+//     rows beyond the map, hold the padding value 0x8000 = below every T(x));
+//   * r2, r4, r6 go to LDS once, ONE barrier, and every pixel reads its column windows directly: 5 + 9 + 13 rows with the row index clamped into the map
+//     (max is idempotent: a clamped duplicate changes nothing, so there is no bounds test);
+//   * three 16-byte stores per pixel into the concat buffer, as before.
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) unsigned int pu32x4;
+typedef __attribute__((ext_vector_type(8))) short ps16x8;
+__device__ __forceinline__ pu32x4 pool_sortable(pu32x4 v)
 {
+    pu32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const unsigned sg = v[i] & 0x80008000u; r[i] = v[i] ^ (sg - (sg >> 15)); }     // per half-word: negative -> flip the low 15 bits (no borrow between the halves)
+    return r;
+}
+__device__ __forceinline__ pu32x4 pool_max(pu32x4 a, pu32x4 b)
+{
+    return __builtin_bit_cast(pu32x4, __builtin_elementwise_max(__builtin_bit_cast(ps16x8, a), __builtin_bit_cast(ps16x8, b)));
+}
+template <int CTRL> __device__ __forceinline__ pu32x4 pool_row_shift(pu32x4 v)
+{
+    pu32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = (unsigned)__builtin_amdgcn_update_dpp((int)0x80008000u, (int)v[i], CTRL, 0xf, 0xf, false);    // lanes without a source keep the padding value
+    return r;
+}
+__device__ __forceinline__ pu32x4 pool_row5(pu32x4 v)           // radius-2 window along the DPP row (= map row)
+{
+    pu32x4 m = pool_max(v, pool_row_shift<0x111>(v));          // row_shr:1 -- lane x <- lane x - 1
+    m = pool_max(m, pool_row_shift<0x112>(v));                 // row_shr:2
+    m = pool_max(m, pool_row_shift<0x101>(v));                 // row_shl:1 -- lane x <- lane x + 1
+    return pool_max(m, pool_row_shift<0x102>(v));              // row_shl:2
+}
+__global__ __launch_bounds__(256) void sppf_pool16_kernel(unsigned short* __restrict__ buf, int cs, int c, int H, int W)
+{
+    __shared__ __attribute__((aligned(16))) pu32x4 rows[3][16][16];       // [radius 2 / 4 / 6][map row][map column]: 12 KB
+    const int x = threadIdx.x & 15, y = threadIdx.x >> 4;
+    const int f = blockIdx.y, c0 = blockIdx.x * 8;
+    const bool in = y < H && x < W;
+    unsigned short* px = buf + ((size_t)f * H * W + (size_t)(in ? y * W + x : 0)) * cs + c0;
+    const pu32x4 pad = {0x80008000u, 0x80008000u, 0x80008000u, 0x80008000u};
+    pu32x4 v = pad;
+    if (in) v = pool_sortable(*reinterpret_cast<const pu32x4*>(px));
+    const pu32x4 r2 = pool_row5(v), r4 = pool_row5(r2), r6 = pool_row5(r4);
+    rows[0][y][x] = r2; rows[1][y][x] = r4; rows[2][y][x] = r6;
+    __syncthreads();
+    if (!in) return;
+    const int ymax = H - 1;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int rad = 2 * k + 2;
+        pu32x4 m = rows[k][y][x];
+#pragma unroll
+        for (int d = 1; d <= rad; ++d) {
+            m = pool_max(m, rows[k][max(y - d, 0)][x]);
+            m = pool_max(m, rows[k][min(y + d, ymax)][x]);
+        }
+        *reinterpret_cast<pu32x4*>(px + (size_t)(k + 1) * c) = pool_sortable(m);
+    }
+}
+
+hipError_t launch_sppf_pool(int dtype, void* buf, int cs, int c, int n, int H, int W, hipStream_t s, int six_pass)
+{
+    constexpr int SPPF_POOL16_MAX_BATCH = 16;
+    // small maps in bf16: the one-barrier kernel (six_pass: the engine's ZLY_SPPF_POOL_LDS=1 switch, tests / A-B)
+    // Small batches only: at batch 1 the launch is 6.8 us against 8.8 (one barrier instead of six on the latency path); at batch 64 it is 13.7 us against 16.5 in
+    // isolation -- both kernels move the map in 16-byte pieces 1 KB apart (an 8-channel slice of a 512-channel NHWC buffer), which is what bounds them
+    // there -- and the three-engine step is 0.8 % SLOWER with it (A/B, 3 alternating rounds), so the big batches keep the six-pass kernel.
+    if (dtype == ZLY_DTYPE_BF16 && H <= 16 && W <= 16 && (c % 8) == 0 && (cs % 8) == 0 && !six_pass && n <= SPPF_POOL16_MAX_BATCH) {
+        hipLaunchKernelGGL(sppf_pool16_kernel, dim3(c / 8, n), dim3(256), 0, s, (unsigned short*)buf, cs, c, H, W);
+        return hipGetLastError();
+    }
+
     const size_t lds = (size_t)H * W * 8 * sizeof(float) * 3;
     if (lds > 160 * 1024 || (c % 8) != 0) return hipErrorInvalidValue;
     dim3 grid(c / 8, n);

@@ -104,7 +104,7 @@ hipError_t launch_c2f64(int mode, const C2fArgs& a, const C2fPlan& plan, hipStre
 hipError_t launch_preprocess(int dtype, const uint8_t* src, const FrameDesc* desc, int n,
                              void* out_nhwc8, float* out_nchw_f32, int tw, int th, hipStream_t s);
 hipError_t launch_nchw_to_nhwc8(int dtype, const float* in_nchw, void* out_nhwc8, int n, int tw, int th, hipStream_t s);
-hipError_t launch_sppf_pool(int dtype, void* buf, int cs, int c, int n, int H, int W, hipStream_t s);
+hipError_t launch_sppf_pool(int dtype, void* buf, int cs, int c, int n, int H, int W, hipStream_t s, int six_pass = 0);      // six_pass: sppf_pool_kernel also on maps of <= 16 x 16 pixels (tests / A-B)
 hipError_t launch_tap_to_nchw(int dtype, const void* in, int cs, int co, int C, int H, int W, int idx, float* out, hipStream_t s);
 
 // kernels_stem.hip -- preprocess fused into the stem conv (bf16, 16-channel stem)
