@@ -356,7 +356,9 @@ __device__ void nms_general(const Cand* gsrc, int n, float iou_thr, int nc, Cand
 #define NMS_WAVE_CAP 128
 
 
-__device__ __forceinline__ void nms_wave(const Cand* __restrict__ gsrc, int n, float iou_thr, Cand* lds, zly_det* dets, int cap, int* n_kept_out)
+// pa / pb: candidates `lane` and `lane + 64` of the frame, loaded by the caller BEFORE the candidate count was known (one global round trip instead of two
+// in a row on the latency path; entries beyond the count are whatever an earlier frame left there and are masked here)
+__device__ __forceinline__ void nms_wave(const Cand& pa, const Cand& pb, int n, float iou_thr, Cand* lds, zly_det* dets, int cap, int* n_kept_out)
 {
     const int lane = threadIdx.x & 63;
     const bool two = n > 64;
@@ -364,8 +366,8 @@ __device__ __forceinline__ void nms_wave(const Cand* __restrict__ gsrc, int n, f
     Cand a, b;
     a.x = a.y = a.w = a.h = 0.f; a.conf = 0.f; a.cls = 0x7fffffff; a.anchor = 0x7fffffff; a.pad_ = 0;
     b = a;
-    if (lane < nA) a = gsrc[lane];
-    if (lane < nB) b = gsrc[lane + 64];
+    if (lane < nA) a = pa;
+    if (lane < nB) b = pb;
     // sort key: (class asc, confidence desc) -- confidences are positive floats, whose bit patterns order like the values -- then the anchor index
     const unsigned ahi = (unsigned)a.cls, alo = ~(unsigned)__float_as_int(a.conf);
     const unsigned bhi = (unsigned)b.cls, blo = ~(unsigned)__float_as_int(b.conf);
@@ -457,9 +459,17 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const Cand* __restrict
 
     const int f = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const Cand* gsrc = cand_all + (size_t)f * N;
+    // wave 0 requests the first 128 candidates before it knows how many there are (the one-wave path below: every realistic frame)
+    Cand pa, pb;
+    pa.x = pa.y = pa.w = pa.h = 0.f; pa.conf = 0.f; pa.cls = 0x7fffffff; pa.anchor = 0x7fffffff; pa.pad_ = 0;
+    pb = pa;
+    if (wave == 0 && !force_general) {
+        if (lane < N) pa = gsrc[lane];
+        if (lane + 64 < N) pb = gsrc[lane + 64];
+    }
     int n = cand_count[f];
     if (n > N) n = N;
-    const Cand* gsrc = cand_all + (size_t)f * N;
     const size_t slab_bytes = sizeof(zly_slab_header) + (size_t)cap * sizeof(zly_det);
     zly_slab_header* hdr = reinterpret_cast<zly_slab_header*>(slabs + (size_t)f * slab_bytes);
     zly_det* dets = reinterpret_cast<zly_det*>(hdr + 1);
@@ -468,7 +478,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const Cand* __restrict
         if (wave != 0) return;
         if (lane == 0) cand_count[f] = 0;              // self-cleaning: the next frame's decode appends from 0 again (no memset launch)
         int kept = 0;
-        nms_wave(gsrc, n, iou_thr, lds_c, dets, cap, &kept);
+        nms_wave(pa, pb, n, iou_thr, lds_c, dets, cap, &kept);
         if (lane == 0) {
             hdr->n_kept = kept; hdr->n_candidates = n;
             hdr->flags = kept > cap ? ZLY_SLAB_OVERFLOW : 0u; hdr->frame_tag = tag0 + (uint32_t)f;
