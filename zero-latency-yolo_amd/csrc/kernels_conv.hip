@@ -84,9 +84,34 @@ __device__ __forceinline__ void epilogue_px(const ConvArgs& a, f32x4 (&v)[CT], c
 // Epilogue of the LDS-tiled kernel (bf16 NHWC output): same arithmetic and channel pairing as epilogue_px, but addresses
 // are 32-bit byte offsets into buffer resources (no 64-bit multiply-add per store; out-of-range is the hardware's check)
 // and the stores carry their offset in the VGPR operand (see the store-hazard note in conv1x1_stream_kernel).
+// The residual fragments epilogue_px_buf will add, requested EARLY (the split-K form asks for them before its k-loop: loaded inside the epilogue they were
+// one more exposed global round trip at the end of the five shortcut convs of a batch-1 step).  Same tiles, same offsets, same widths as the epilogue's loads.
 template <int CT>
+__device__ __forceinline__ void prefetch_res_buf(const ConvArgs& a, __amdgpu_buffer_rsrc_t rres, int tile0, int kq, int m, u32x4 (&rq)[CT])
+{
+    const int ntiles = (a.Cout + 15) >> 4;
+    const int paired = (ntiles >> 1) << 1;
+    const int rb = (m * a.res_cs + a.res_co) * 2;
+    const bool even0 = (tile0 & 1) == 0;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        rq[c] = u32x4{0u, 0u, 0u, 0u};
+        const int tile = tile0 + c;
+        const int ch = tile_channel(tile, kq, paired);
+        if (ch >= a.Cout) continue;
+        const bool pair_here = even0 && (c % 2 == 0) && (c + 1 < CT) && (tile + 1 < paired);
+        if (pair_here) rq[c] = __builtin_amdgcn_raw_buffer_load_b128(rres, rb + ch * 2, 0, 0);
+        else if (!(even0 && (c % 2 == 1) && (tile < paired))) {
+            typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+            const u32x2 r2 = __builtin_amdgcn_raw_buffer_load_b64(rres, rb + ch * 2, 0, 0);
+            rq[c][0] = r2[0]; rq[c][1] = r2[1];
+        }
+    }
+}
+
+template <int CT, bool PRE = false>
 __device__ __forceinline__ void epilogue_px_buf(const ConvArgs& a, __amdgpu_buffer_rsrc_t rout, __amdgpu_buffer_rsrc_t rres,
-                                                f32x4 (&v)[CT], const f32x4 (&bias)[CT], int tile0, int kq, int m)
+                                                f32x4 (&v)[CT], const f32x4 (&bias)[CT], int tile0, int kq, int m, const u32x4* rq = nullptr)
 {
     const int ntiles = (a.Cout + 15) >> 4;
     const int paired = (ntiles >> 1) << 1;
@@ -112,7 +137,7 @@ __device__ __forceinline__ void epilogue_px_buf(const ConvArgs& a, __amdgpu_buff
         if (pair_here) {
             f32x4 lo = o[c], hi = o[c + 1 < CT ? c + 1 : c];
             if (a.res) {
-                const bf16x8 r = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rres, rb + ch * 2, 0, 0));
+                const bf16x8 r = __builtin_bit_cast(bf16x8, PRE ? rq[c] : __builtin_amdgcn_raw_buffer_load_b128(rres, rb + ch * 2, 0, 0));
                 lo += f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
                 hi += f32x4{(float)r[4], (float)r[5], (float)r[6], (float)r[7]};
             }
@@ -121,7 +146,8 @@ __device__ __forceinline__ void epilogue_px_buf(const ConvArgs& a, __amdgpu_buff
         } else if (!(even0 && (c % 2 == 1) && (tile < paired))) {      // second tile of a pair already written above
             f32x4 x = o[c];
             if (a.res) {
-                const bf16x4 r = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(rres, rb + ch * 2, 0, 0));
+                typedef __attribute__((ext_vector_type(2))) unsigned int u32x2r;
+                const bf16x4 r = __builtin_bit_cast(bf16x4, PRE ? u32x2r{rq[c][0], rq[c][1]} : __builtin_amdgcn_raw_buffer_load_b64(rres, rb + ch * 2, 0, 0));
                 x += f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
             }
             const bf16x4 w = to_bf16x4(x);
@@ -206,6 +232,10 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a)
     const T* __restrict__ wp = static_cast<const T*>(a.wgt) +
                                (size_t)(blockIdx.y * CT) * a.nk * WTILE + lane * EPL;
 
+    // split-K form: inputs through buffer resources (32-bit byte offsets: launch_conv sends tensors of 2 GiB or more to the KSPLIT = 1 shapes)
+    const __amdgpu_buffer_rsrc_t rin1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(in), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rin2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(in2 ? in2 : in), 0, 0x7fffffff, 0x00020000);
+    (void)rin1; (void)rin2;
     // MODE 1 running position of the NEXT step to be loaded (wave-uniform)
     int tap = 0, cbase = 0;
     if (MODE == 1) { const int k0 = s_begin * KSTEP; tap = k0 / a.Cin; cbase = k0 - tap * a.Cin; }
@@ -236,8 +266,21 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a)
             F z;
 #pragma unroll
             for (int j = 0; j < EPL; ++j) z[j] = (T)0.0f;
-            const T* src = (dual && ci >= a.split_c) ? in2 + (long)(boff2[t] + koff) : in + (long)(boff[t] + koff);
-            af[t] = ok ? *reinterpret_cast<const F*>(src) : z;
+            if constexpr (KSPLIT > 1) {
+                // The latency path: NO branch around the load.  `ok ? *src : zero` became an exec-masked block with the load and a register move
+                // inside it, i.e. `s_waitcnt vmcnt(0)` right behind the first k-step's load -- a full global round trip before the other k-steps'
+                // loads were even requested, in every one of the ~30 split-K launches of a batch-1 step.  A buffer load takes the mask as an
+                // out-of-range offset (the range check returns zeros): straight-line code, every k-step of the ring requested back to back.
+                // Which source a k-step reads is wave-uniform (split_c is a multiple of the k-step): a scalar select of the resource.
+                const bool src2 = MODE == 0 && dual && s * KSTEP >= a.split_c;
+                const int eoff = src2 ? boff2[t] + koff : boff[t] + koff;
+                const unsigned boff_bytes = ok ? (unsigned)eoff * (unsigned)sizeof(T) : 0x80000000u;
+                af[t] = __builtin_bit_cast(F, __builtin_amdgcn_raw_buffer_load_b128(src2 ? rin2 : rin1, (int)boff_bytes, 0, 0));
+                (void)z;
+            } else {
+                const T* src = (dual && ci >= a.split_c) ? in2 + (long)(boff2[t] + koff) : in + (long)(boff[t] + koff);
+                af[t] = ok ? *reinterpret_cast<const F*>(src) : z;
+            }
         }
     };
     auto mma_all = [&](const F (&wf)[CT], const F (&af)[PT]) {
@@ -249,6 +292,21 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a)
 
     f32x4 biasr[CT];
     load_bias<CT>(a, blockIdx.y * CT, kq, biasr);         // in flight during the k-loop
+    // split-K form, bf16 NHWC output with a shortcut: wave 0 (the one that runs the epilogue) asks for the residual now
+    constexpr bool RESPRE = KSPLIT > 1 && sizeof(T) == 2;
+    u32x4 resq[PT][CT];
+    __amdgpu_buffer_rsrc_t rres_early = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.res ? a.res : a.out), 0,
+                                                                          (unsigned)((size_t)a.M * (a.res ? a.res_cs : a.out_cs) * sizeof(T)), 0x00020000);
+    if constexpr (RESPRE) {
+        if (a.res && !a.out_f32 && wave == 0) {
+#pragma unroll
+            for (int t = 0; t < PT; ++t) {
+                const int m = m_base + t * 16 + p;
+                prefetch_res_buf<CT>(a, rres_early, blockIdx.y * CT, kq, m < a.M ? m : 0, resq[t]);
+            }
+        }
+    }
+    (void)rres_early; (void)resq;
     if constexpr (KSPLIT > 1) {
         // split-K (the latency path): a wave's quarter of K is 1 .. 18 k-steps and its launch lasts as long as this chain -- with two steps in
         // flight that was (steps / 2) dependent L2 round trips (wave lifetime 2.5 us of a 4.8 us launch at batch 1).  A ring of DEPTH register
@@ -315,7 +373,11 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a)
 #pragma unroll
         for (int c = 0; c < CT; ++c) v[c] = acc[c][t];
         if constexpr (sizeof(T) == 2) {
-            if (!a.out_f32) { epilogue_px_buf<CT>(a, rout, rres, v, biasr, blockIdx.y * CT, kq, m); continue; }     // bf16 NHWC output: 32-bit buffer offsets
+            if (!a.out_f32) {                                                                                      // bf16 NHWC output: 32-bit buffer offsets
+                if constexpr (RESPRE) epilogue_px_buf<CT, true>(a, rout, rres, v, biasr, blockIdx.y * CT, kq, m, resq[t]);
+                else                  epilogue_px_buf<CT>(a, rout, rres, v, biasr, blockIdx.y * CT, kq, m);
+                continue;
+            }
         }
         epilogue_px<T, CT>(a, v, biasr, blockIdx.y * CT, kq, m);
     }
@@ -346,6 +408,7 @@ hipError_t launch_conv_multi(const ConvArgsMulti& m, int ct, hipStream_t s)
     for (int i = 0; i < m.n; ++i) {
         const ConvArgs& a = m.a[i];
         if (a.Cin % 32 || a.pad != 1 || a.in2 || a.out_f32 || a.cout_pad % (16 * ct)) return hipErrorInvalidValue;
+        if ((size_t)(a.M / (a.Ho * a.Wo)) * a.H * a.W * (size_t)a.in_cs * 2 >= ((size_t)1 << 31)) return hipErrorInvalidValue;     // 32-bit buffer offsets (batch <= 4 launches: far below)
         gx = gx > (a.M + 15) / 16 ? gx : (a.M + 15) / 16;
         gy = gy > a.cout_pad / (16 * ct) ? gy : a.cout_pad / (16 * ct);
     }
@@ -1955,8 +2018,11 @@ hipError_t launch_conv(int dtype, const ConvArgs& a, const ConvLaunch& cfg, hipS
     }
     const int mode = cfg.ks == 1 ? 0 : (cfg.fastk ? 1 : 2);
     conv_fn fn = nullptr;
+    // the split-K kernel reads its inputs through 32-bit buffer offsets: an input tensor of 2 GiB or more (never a latency-path launch) takes the one-pass shape
+    const size_t in_bytes = (size_t)(a.M / (a.Ho * a.Wo)) * a.H * a.W * (size_t)std::max(a.in_cs, a.in2 ? a.in2_cs : 0) * 2;
+    const bool split = cfg.ksplit == 4 && in_bytes < ((size_t)1 << 31);
     if (dtype == ZLY_DTYPE_BF16) {
-        if (cfg.ksplit == 4)   fn = pick_mode<bf16_t, 1, 4>(mode, cfg.ct);
+        if (split)             fn = pick_mode<bf16_t, 1, 4>(mode, cfg.ct);
         else if (cfg.pt == 1)  fn = pick_mode<bf16_t, 1, 1>(mode, cfg.ct);
         else if (cfg.pt == 2)  fn = pick_mode<bf16_t, 2, 1>(mode, cfg.ct);
         else                   fn = pick_mode<bf16_t, 4, 1>(mode, cfg.ct);
@@ -1966,7 +2032,7 @@ hipError_t launch_conv(int dtype, const ConvArgs& a, const ConvLaunch& cfg, hipS
     if (!fn) return hipErrorInvalidValue;
     const int cout_pad = a.cout_pad;
     const int ytiles = cout_pad / (16 * cfg.ct);
-    const int px_per_wg = cfg.ksplit == 4 ? 16 * cfg.pt : 64 * cfg.pt;
+    const int px_per_wg = split ? 16 * cfg.pt : 64 * cfg.pt;
     dim3 grid((a.M + px_per_wg - 1) / px_per_wg, ytiles, 1);
     hipLaunchKernelGGL(fn, grid, dim3(256), 0, s, a);
     return hipGetLastError();
