@@ -739,6 +739,7 @@ static ConvArgs make_conv_args(zly_engine* e, const Op& op, int n)
     a.stride = op.stride; a.pad = op.ks / 2;
     a.K = op.K; a.nk = op.nk; a.M = n * ob.H * ob.W; a.act = op.act; a.out_f32 = op.out_f32;
     a.in2 = nullptr; a.in2_cs = 0; a.in2_co = 0; a.split_c = 0;
+    a.inv_wo = 0.f; a.inv_ho = 0.f;                                   // filled where the split-K kernel is launched
     if (op.in2.buf >= 0) {
         const Buffer& i2 = e->bufs[(size_t)op.in2.buf];
         a.in2 = i2.ptr; a.in2_cs = i2.C; a.in2_co = op.in2.co; a.split_c = op.in.C;

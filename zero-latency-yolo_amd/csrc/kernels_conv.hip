@@ -209,10 +209,20 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a)
             boff[t] = mm * a.in_cs + a.in_co;
             continue;
         }
-        const int ox = mm % a.Wo;
-        const int r = mm / a.Wo;
-        const int oy = r % a.Ho;
-        const int b = r / a.Ho;
+        int ox, oy, b;
+        if constexpr (KSPLIT > 1) {
+            // split-K form (small M by construction): (b, oy, ox) by reciprocal multiplies -- exact for m < 2^20 and maps of < 2^10 pixels a side, which
+            // launch_conv checks -- instead of two emulated 32-bit divisions in front of the first load of a ~3 us launch
+            const int r = (int)(((float)mm + 0.5f) * a.inv_wo);
+            ox = mm - r * a.Wo;
+            b = (int)(((float)r + 0.5f) * a.inv_ho);
+            oy = r - b * a.Ho;
+        } else {
+            ox = mm % a.Wo;
+            const int r = mm / a.Wo;
+            oy = r % a.Ho;
+            b = r / a.Ho;
+        }
         iy0[t] = oy * a.stride - a.pad;
         ix0[t] = ox * a.stride - a.pad;
         boff[t] = ((b * a.H + iy0[t]) * a.W + ix0[t]) * a.in_cs + a.in_co;
@@ -412,8 +422,13 @@ hipError_t launch_conv_multi(const ConvArgsMulti& m, int ct, hipStream_t s)
         gx = gx > (a.M + 15) / 16 ? gx : (a.M + 15) / 16;
         gy = gy > a.cout_pad / (16 * ct) ? gy : a.cout_pad / (16 * ct);
     }
-    if (ct == 2) hipLaunchKernelGGL(conv_igemm_multi_kernel<2>, dim3(gx, gy, m.n), dim3(256), 0, s, m);
-    else         hipLaunchKernelGGL(conv_igemm_multi_kernel<3>, dim3(gx, gy, m.n), dim3(256), 0, s, m);
+    ConvArgsMulti mm = m;
+    for (int i = 0; i < mm.n; ++i) {
+        if (mm.a[i].M >= (1 << 20) || mm.a[i].Wo >= 1024 || mm.a[i].Ho >= 1024) return hipErrorInvalidValue;       // reciprocal index arithmetic of the split-K form
+        mm.a[i].inv_wo = 1.0f / (float)mm.a[i].Wo; mm.a[i].inv_ho = 1.0f / (float)mm.a[i].Ho;
+    }
+    if (ct == 2) hipLaunchKernelGGL(conv_igemm_multi_kernel<2>, dim3(gx, gy, mm.n), dim3(256), 0, s, mm);
+    else         hipLaunchKernelGGL(conv_igemm_multi_kernel<3>, dim3(gx, gy, mm.n), dim3(256), 0, s, mm);
     return hipGetLastError();
 }
 
@@ -2020,7 +2035,7 @@ hipError_t launch_conv(int dtype, const ConvArgs& a, const ConvLaunch& cfg, hipS
     conv_fn fn = nullptr;
     // the split-K kernel reads its inputs through 32-bit buffer offsets: an input tensor of 2 GiB or more (never a latency-path launch) takes the one-pass shape
     const size_t in_bytes = (size_t)(a.M / (a.Ho * a.Wo)) * a.H * a.W * (size_t)std::max(a.in_cs, a.in2 ? a.in2_cs : 0) * 2;
-    const bool split = cfg.ksplit == 4 && in_bytes < ((size_t)1 << 31);
+    const bool split = cfg.ksplit == 4 && in_bytes < ((size_t)1 << 31) && a.M < (1 << 20) && a.Wo < 1024 && a.Ho < 1024;
     if (dtype == ZLY_DTYPE_BF16) {
         if (split)             fn = pick_mode<bf16_t, 1, 4>(mode, cfg.ct);
         else if (cfg.pt == 1)  fn = pick_mode<bf16_t, 1, 1>(mode, cfg.ct);
@@ -2034,7 +2049,9 @@ hipError_t launch_conv(int dtype, const ConvArgs& a, const ConvLaunch& cfg, hipS
     const int ytiles = cout_pad / (16 * cfg.ct);
     const int px_per_wg = split ? 16 * cfg.pt : 64 * cfg.pt;
     dim3 grid((a.M + px_per_wg - 1) / px_per_wg, ytiles, 1);
-    hipLaunchKernelGGL(fn, grid, dim3(256), 0, s, a);
+    ConvArgs b = a;
+    b.inv_wo = 1.0f / (float)a.Wo; b.inv_ho = 1.0f / (float)a.Ho;
+    hipLaunchKernelGGL(fn, grid, dim3(256), 0, s, b);
     return hipGetLastError();
 }
 

@@ -30,6 +30,18 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define STEM_PH (STEM_TH * 2 + 1)
 #define STEM_PW (STEM_TW * 2 + 1)
 
+// A frame descriptor in ONE 16-byte scalar load.  Read field by field the compiler fetched src_off and w, compared w, and only then asked for h (the
+// short-circuit of `w == tw && h == th`): a second dependent round trip to memory in front of every tile's first pixel load.
+__device__ __forceinline__ FrameDesc load_desc(const FrameDesc* p)
+{
+    typedef unsigned int du32x4 __attribute__((ext_vector_type(4)));
+    const du32x4 q = *reinterpret_cast<const du32x4*>(p);
+    FrameDesc d;
+    d.src_off = (unsigned long long)q[0] | ((unsigned long long)q[1] << 32);
+    d.w = (int)q[2]; d.h = (int)q[3];
+    return d;
+}
+
 // NT = output channel tiles of 16: 1 (YOLOv8n, 16-channel stem: rows in channel order) or 2 (YOLOv8-s, 32 channels: pair-permuted rows, a lane
 // ends with 8 consecutive channels = one 16-byte store); the pixel fragments are read once for both tiles
 template <int NT>
@@ -52,11 +64,11 @@ __global__ __launch_bounds__(256) void stem_fused_kernel(const StemArgs a)
 #pragma unroll
         for (int s = 0; s < 2; ++s) w[t][s] = *reinterpret_cast<const bf16x8*>(static_cast<const bf16_t*>(a.wgt) + (t * 2 + s) * 512 + lane * 8);
 
-    const FrameDesc d = a.desc[f];
+    const FrameDesc d = load_desc(&a.desc[f]);
     const float scale_w = (float)d.w / (float)a.tw;
     const float scale_h = (float)d.h / (float)a.th;
     const uint8_t* src = a.src + d.src_off;
-    const bool same = d.w == a.tw && d.h == a.th;
+    const bool same = (d.w == a.tw) & (d.h == a.th);
     const size_t frame_bytes = (size_t)d.w * d.h * 3;
     for (int u = tid; u < STEM_PH * STEM_PW; u += 256) {
         const int py = u / STEM_PW, px = u - py * STEM_PW;
@@ -288,8 +300,8 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 8 : NW == 12 ? 6 : 4) void stem
         int f, oy1, ox1;
         tile_origin(tile, f, oy1, ox1);
         const int iy0 = 4 * oy1 - 3, ix0 = 4 * ox1 - 3;
-        const FrameDesc d = a.st.desc[f];
-        if (!(d.w == a.st.tw && d.h == a.st.th)) return;     // resized frame: the general path below does its own loads
+        const FrameDesc d = load_desc(&a.st.desc[f]);
+        if (!((d.w == a.st.tw) & (d.h == a.st.th))) return;     // resized frame: the general path below does its own loads
         const uint8_t* src = a.st.src + d.src_off;
         pma = issue_quad(qok[0], qpy[0], qpx[0], iy0, ix0, d, src, pa0, pa1, pa2);
         pmb = issue_quad(qok[1], qpy[1], qpx[1], iy0, ix0, d, src, pb0, pb1, pb2);
@@ -320,9 +332,9 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 8 : NW == 12 ? 6 : 4) void stem
     const int iy0 = 2 * sy0 - 1, ix0 = 2 * sx0 - 1;          // input patch origin (model-input pixel coordinates)
 
     // ---- 1. input patch ------------------------------------------------------------------------------------------
-    const FrameDesc d = a.st.desc[f];
+    const FrameDesc d = load_desc(&a.st.desc[f]);
     const uint8_t* src = a.st.src + d.src_off;
-    const bool same = d.w == a.st.tw && d.h == a.st.th;
+    const bool same = (d.w == a.st.tw) & (d.h == a.st.th);
     const size_t frame_bytes = (size_t)d.w * d.h * 3;
     STEMSTAMP(0);
     if (same && NEWP) {

@@ -19,25 +19,34 @@ struct FrameDesc {
 // "view" is a channel slice [co, co+C) of a buffer whose pixels are `cs` elements apart, which is
 // how C2f split / Concat cost nothing.
 struct ConvArgs {
-    const void* in;   int in_cs, in_co;
-    int H, W;                     // input spatial size
-    int Cin;                      // input channels as stored (multiple of 8)
-    const void* wgt;              // tiled [CoutPad/16][Kpad/KSTEP][16][KSTEP]
-    const float* bias;            // [CoutPad]
-    void* out;        int out_cs, out_co;
-    int Ho, Wo, Cout;
-    int cout_pad;                 // output channels the weight tiles cover (multiple of 16, >= Cout; may include whole zero tiles so that the tile count suits a kernel's channel blocking)
-    const void* res;  int res_cs, res_co;    // optional residual (added after the activation)
-    int stride, pad;
-    int K;                        // ks*ks*Cin
-    int nk;                       // Kpad / KSTEP
-    int M;                        // batch*Ho*Wo
-    int act;                      // 1 = SiLU
-    int out_f32;                  // 1 = write fp32 regardless of the activation dtype
+    // Field ORDER matters on the latency path: kernel arguments are fetched by scalar loads where they are first used, adjacent fields by one wide load, and
+    // every further round (s_load ... s_waitcnt) in front of a ~3 us launch's first global load is ~0.1 us, thirty times per batch-1 step (measured: the two
+    // reciprocals at the END of this struct cost the step 2.4 %, next to Wo / Ho they gain 1 %).  So: what the index arithmetic and the first loads need
+    // comes first, in the order of use; what only the epilogue needs comes last.
+    const void* in;               // input tensor (NHWC)
     // 1x1 convs only: fused "nearest-2x Upsample + Concat" input (yolov8.yaml layers 10-11, 13-14).  When in2 is
     // set, input channels [0, split_c) are read from `in`, a tensor of HALF the spatial size, at (y>>1, x>>1),
     // and channels [split_c, Cin) from `in2` at full size.  split_c is a multiple of the k-step.
-    const void* in2;  int in2_cs, in2_co, split_c;
+    const void* in2;
+    const void* wgt;              // tiled [CoutPad/16][Kpad/KSTEP][16][KSTEP]
+    const float* bias;            // [CoutPad] (requested before the k-loop: with the hot fields)
+    int M;                        // batch*Ho*Wo
+    int nk;                       // Kpad / KSTEP
+    int Ho, Wo;
+    float inv_wo, inv_ho;         // 1 / Wo, 1 / Ho: set by launch_conv / launch_conv_multi for the split-K kernel (index arithmetic by reciprocal multiplies)
+    int stride, pad;
+    int H, W;                     // input spatial size
+    int in_cs, in_co;
+    int Cin;                      // input channels as stored (multiple of 8)
+    int in2_cs, in2_co, split_c;
+    int K;                        // ks*ks*Cin
+    // ---- epilogue ----
+    void* out;        int out_cs, out_co;
+    int Cout;
+    int cout_pad;                 // output channels the weight tiles cover (multiple of 16, >= Cout; may include whole zero tiles so that the tile count suits a kernel's channel blocking)
+    const void* res;  int res_cs, res_co;    // optional residual (added after the activation)
+    int act;                      // 1 = SiLU
+    int out_f32;                  // 1 = write fp32 regardless of the activation dtype
 };
 
 struct ConvLaunch { int ks, ct, pt, fastk, ksplit, lds, stream, wres, ps, ws1, rowt, tpw1; };   // rowt: weight-stationary 3x3 kernel's row-tile form (ZLY_WS_ROWT, read when the shape is picked)
