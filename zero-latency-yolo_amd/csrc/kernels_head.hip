@@ -9,6 +9,7 @@
 // round trip through HBM.  decode here and decode_kernel (kernels_post.hip, used by zly_postprocess)
 // apply the same comparisons to the same fp32 values, so both give the same candidates.
 #include "zly_internal.h"
+#include <algorithm>
 #include <math.h>
 
 #pragma clang fp contract(off)
@@ -76,31 +77,68 @@ __global__ __launch_bounds__(HEAD_WAVES * 64) void head_fused_kernel(const HeadA
     F zero;
 #pragma unroll
     for (int j = 0; j < EPL; ++j) zero[j] = (T)0.0f;
+    // the two branch tensors of this level as buffer resources (a.buf32: every level below 2 GiB, set by launch_head_fused)
+    const __amdgpu_buffer_rsrc_t rcls = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(L.cls_in), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rbox = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(L.box_in), 0, 0x7fffffff, 0x00020000);
 
-    // class-branch fragments of the tile, every k-step, requested up front
     constexpr int KMAX = HEAD_KMAX;                          // k-steps of a branch: bf16 80/128 channels -> 3/4, fp32 -> 5/8 (launch_head_fused refuses more)
-    F xc[KMAX];
-    {
-        const T* pc = static_cast<const T*>(L.cls_in) + pix * L.cls_cs;
-#pragma unroll
-        for (int s = 0; s < KMAX; ++s) {
-            const int ci = s * KSTEP + kq * EPL;
-            xc[s] = zero;
-            if (s < L.nkc && valid && ci < L.cls_cin) xc[s] = *reinterpret_cast<const F*>(pc + ci);
-        }
-    }
     // weights -> LDS: [box: 4 x nkb tiles][class: CTC x nkc tiles], 1 KiB each, already in MFMA lane order
     T* lwb = reinterpret_cast<T*>(smem);
     T* lwc = lwb + (size_t)4 * L.nkb * WTILE;
+    const int nb16 = 4 * L.nkb * 64, nc16 = CTC * L.nkc * 64;          // 16-byte units
+    const uint4* gb = reinterpret_cast<const uint4*>(L.wb);
+    const uint4* gc = reinterpret_cast<const uint4*>(L.wc);
+    uint4* sb4 = reinterpret_cast<uint4*>(lwb);
+    uint4* sc4 = reinterpret_cast<uint4*>(lwc);
+    // every unit of this thread requested before the first LDS store: `for (u ...) lds[u] = g[u]` compiled to load -> s_waitcnt vmcnt(0) -> ds_write per
+    // iteration, six global round trips in a row at the head of every workgroup (2 + 4 iterations for the 64 / 80-channel branches).  Buffer loads:
+    // units beyond the tile count are out of range (no memory access), the stores stay guarded.
+    constexpr int NT = HEAD_WAVES * 64;
+    constexpr int NB_T = (4 * KMAX * 64 + NT - 1) / NT, NC_T = (CTC * KMAX * 64 + NT - 1) / NT;
+    const __amdgpu_buffer_rsrc_t rwb = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(L.wb), 0, (unsigned)nb16 * 16u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rwc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(L.wc), 0, (unsigned)nc16 * 16u, 0x00020000);
+    (void)gb; (void)gc;
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+    u32x4 tb[NB_T], tc[NC_T];
+#pragma unroll
+    for (int i = 0; i < NB_T; ++i) if (i * NT < nb16) tb[i] = __builtin_amdgcn_raw_buffer_load_b128(rwb, (int)((threadIdx.x + i * NT) * 16), 0, 0);      // scalar test: whole rounds beyond the branch's tiles are skipped
+#pragma unroll
+    for (int i = 0; i < NC_T; ++i) if (i * NT < nc16) tc[i] = __builtin_amdgcn_raw_buffer_load_b128(rwc, (int)((threadIdx.x + i * NT) * 16), 0, 0);
+    // (the weight loads above and the class fragments below are in flight together; the LDS stores of the weights follow the fragment requests)
+    // class-branch fragments of the tile, every k-step, requested up front
+    F xc[KMAX];
     {
-        const int nb16 = 4 * L.nkb * 64, nc16 = CTC * L.nkc * 64;          // 16-byte units
-        const uint4* gb = reinterpret_cast<const uint4*>(L.wb);
-        const uint4* gc = reinterpret_cast<const uint4*>(L.wc);
-        uint4* sb4 = reinterpret_cast<uint4*>(lwb);
-        uint4* sc4 = reinterpret_cast<uint4*>(lwc);
-        for (int u = threadIdx.x; u < nb16; u += HEAD_WAVES * 64) sb4[u] = gb[u];
-        for (int u = threadIdx.x; u < nc16; u += HEAD_WAVES * 64) sc4[u] = gc[u];
+        const T* pc = static_cast<const T*>(L.cls_in) + pix * L.cls_cs;
+        // No branch around a load: `if (valid && ...) x = *p` compiled to exec-masked blocks with `s_waitcnt vmcnt(0)` behind every second load -- the k-steps
+        // of a tile were fetched in a chain of global round trips at the head of every workgroup.  With 32-bit offsets available (a.buf32, every realistic
+        // batch) the lane mask goes into the offset of a buffer load (out of range -> zeros) and only the k-step test stays, as a scalar branch.
+        if (a.buf32) {
+#pragma unroll
+            for (int s = 0; s < KMAX; ++s) {
+                const int ci = s * KSTEP + kq * EPL;
+                xc[s] = zero;
+                if (s < L.nkc) {
+                    const unsigned off = (valid && ci < L.cls_cin) ? (unsigned)((pix * L.cls_cs + ci) * sizeof(T)) : 0x80000000u;
+                    xc[s] = __builtin_bit_cast(F, __builtin_amdgcn_raw_buffer_load_b128(rcls, (int)off, 0, 0));
+                }
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < KMAX; ++s) {
+                const int ci = s * KSTEP + kq * EPL;
+                xc[s] = zero;
+                if (s < L.nkc && valid && ci < L.cls_cin) xc[s] = *reinterpret_cast<const F*>(pc + ci);
+            }
+        }
     }
+    // class biases of this lane's rows: requested with everything else (loaded where they are added they were one more round trip between the class GEMM and the early-out)
+    f32x4 bcls[CTC];
+#pragma unroll
+    for (int c = 0; c < CTC; ++c) bcls[c] = *reinterpret_cast<const f32x4*>(L.bc + c * 16 + kq * 4);
+#pragma unroll
+    for (int i = 0; i < NB_T; ++i) { const int u = threadIdx.x + i * NT; if (i * NT < nb16 && u < nb16) *reinterpret_cast<u32x4*>(sb4 + u) = tb[i]; }
+#pragma unroll
+    for (int i = 0; i < NC_T; ++i) { const int u = threadIdx.x + i * NT; if (i * NT < nc16 && u < nc16) *reinterpret_cast<u32x4*>(sc4 + u) = tc[i]; }
     __syncthreads();
     if (!active) return;
 
@@ -126,7 +164,7 @@ __global__ __launch_bounds__(HEAD_WAVES * 64) void head_fused_kernel(const HeadA
 #pragma unroll
         for (int c = 0; c < CTC; ++c) {
             const int ch = c * 16 + kq * 4;
-            const f32x4 bias = *reinterpret_cast<const f32x4*>(L.bc + ch);
+            const f32x4 bias = bcls[c];
 #pragma unroll
             for (int r = 0; r < 4; ++r) if (ch + r < a.nc) zmax = fmaxf(zmax, accc[c][r] + bias[r]);
         }
@@ -141,11 +179,23 @@ __global__ __launch_bounds__(HEAD_WAVES * 64) void head_fused_kernel(const HeadA
     {
         F xb[KMAX];
         const T* pb = static_cast<const T*>(L.box_in) + pix * L.box_cs;
+        if (a.buf32) {
 #pragma unroll
-        for (int s = 0; s < KMAX; ++s) {
-            const int ci = s * KSTEP + kq * EPL;
-            xb[s] = zero;
-            if (s < L.nkb && valid && ci < L.box_cin) xb[s] = *reinterpret_cast<const F*>(pb + ci);
+            for (int s = 0; s < KMAX; ++s) {
+                const int ci = s * KSTEP + kq * EPL;
+                xb[s] = zero;
+                if (s < L.nkb) {
+                    const unsigned off = (valid && ci < L.box_cin) ? (unsigned)((pix * L.box_cs + ci) * sizeof(T)) : 0x80000000u;
+                    xb[s] = __builtin_bit_cast(F, __builtin_amdgcn_raw_buffer_load_b128(rbox, (int)off, 0, 0));
+                }
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < KMAX; ++s) {
+                const int ci = s * KSTEP + kq * EPL;
+                xb[s] = zero;
+                if (s < L.nkb && valid && ci < L.box_cin) xb[s] = *reinterpret_cast<const F*>(pb + ci);
+            }
         }
         const T* w = lwb + lane * EPL;
 #pragma unroll
@@ -193,7 +243,7 @@ __global__ __launch_bounds__(HEAD_WAVES * 64) void head_fused_kernel(const HeadA
 #pragma unroll
     for (int c = 0; c < CTC; ++c) {
         const int ch = c * 16 + kq * 4;
-        const f32x4 bias = *reinterpret_cast<const f32x4*>(L.bc + ch);
+        const f32x4 bias = bcls[c];
         const f32x4 z = accc[c] + bias;
         accc[c] = z;
 #pragma unroll
@@ -281,6 +331,11 @@ hipError_t launch_head_fused(int dtype, const HeadArgs& a0, int n, hipStream_t s
     if (lds > 64 * 1024) return hipErrorInvalidValue;
     for (int l = 0; l < 3; ++l)
         if (a.lv[l].nkb > HEAD_KMAX || a.lv[l].nkc > HEAD_KMAX) return hipErrorInvalidValue;      // the kernel holds a branch's fragments in HEAD_KMAX k-steps of registers: a wider branch would lose its tail k-steps silently
+    a.buf32 = 1;
+    for (int l = 0; l < 3; ++l) {
+        const size_t el = dtype == ZLY_DTYPE_BF16 ? 2 : 4;
+        if ((size_t)n * a.lv[l].hw * (size_t)std::max(a.lv[l].box_cs, a.lv[l].cls_cs) * el >= ((size_t)1 << 31)) a.buf32 = 0;      // 32-bit offsets would not reach: pointer loads
+    }
     const int blocks = a.only_level >= 0 ? (a.lv[a.only_level].hw + HEAD_GROUP - 1) / HEAD_GROUP : a.total_blocks;
     hipLaunchKernelGGL(fn, dim3(blocks, n), dim3(HEAD_WAVES * 64), lds, s, a);
     return hipGetLastError();

@@ -183,6 +183,7 @@ struct HeadArgs {
     float skip_logit;                         // set by launch_head_fused: class logit below which no score reaches conf_thr
     int diag;                                 // diagnostic builds only (tools/head_bench.hip); 0 in the product
     struct Cand* cand; int* cand_count;
+    int buf32;                                // set by launch_head_fused: every level's branch tensors are below 2 GiB -> fragments by buffer loads (lane mask as an out-of-range offset)
 };
 hipError_t launch_head_fused(int dtype, const HeadArgs& a, int n, hipStream_t s);
 
