@@ -393,6 +393,8 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a)
     }
 }
 
+// (Fetching the arguments up front -- all of them, or only the ~100 bytes the index arithmetic needs -- was measured SLOWER than the compiler's fetch-at-first-use on
+// the batch-1 step: +2.4 % / +1.3 %.  What helps is the ORDER of the fields in ConvArgs: zly_internal.h.)
 template <typename T, int MODE, int CT, int PT, int KSPLIT>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
 {
@@ -407,7 +409,7 @@ template <int CT>
 __global__ __launch_bounds__(256) void conv_igemm_multi_kernel(const ConvArgsMulti m)
 {
     const ConvArgs& a = m.a[blockIdx.z];
-    if ((int)blockIdx.y * CT * 16 >= a.cout_pad || (int)blockIdx.x * 16 >= a.M) return;      // block-uniform: beyond this conv's extent
+    if (((int)blockIdx.y * CT * 16 >= a.cout_pad) | ((int)blockIdx.x * 16 >= a.M)) return;   // block-uniform: beyond this conv's extent
     conv_igemm_body<bf16_t, 1, CT, 1, 4>(a);
 }
 

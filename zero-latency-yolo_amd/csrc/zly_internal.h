@@ -31,6 +31,7 @@ struct ConvArgs {
     const void* wgt;              // tiled [CoutPad/16][Kpad/KSTEP][16][KSTEP]
     const float* bias;            // [CoutPad] (requested before the k-loop: with the hot fields)
     int M;                        // batch*Ho*Wo
+    int cout_pad;                 // output channels the weight tiles cover (multiple of 16, >= Cout; may include whole zero tiles so that the tile count suits a kernel's channel blocking); read first by the multi-conv kernel's extent test
     int nk;                       // Kpad / KSTEP
     int Ho, Wo;
     float inv_wo, inv_ho;         // 1 / Wo, 1 / Ho: set by launch_conv / launch_conv_multi for the split-K kernel (index arithmetic by reciprocal multiplies)
@@ -43,7 +44,6 @@ struct ConvArgs {
     // ---- epilogue ----
     void* out;        int out_cs, out_co;
     int Cout;
-    int cout_pad;                 // output channels the weight tiles cover (multiple of 16, >= Cout; may include whole zero tiles so that the tile count suits a kernel's channel blocking)
     const void* res;  int res_cs, res_co;    // optional residual (added after the activation)
     int act;                      // 1 = SiLU
     int out_f32;                  // 1 = write fp32 regardless of the activation dtype
