@@ -167,9 +167,20 @@ __device__ __forceinline__ void epilogue_px_buf(const ConvArgs& a, __amdgpu_buff
 //              4x shorter dependent load->MFMA chain, which is what bounds those launches.
 // The k-loop is software pipelined by hand: fragments of step s+1 are requested before the MFMAs of
 // step s issue (two named register sets, statically indexed).
+#ifdef ZLY_IGEMM_DIAG
+__device__ unsigned long long* g_igemm_diag = nullptr;           // diagnostic build only (tools/igemm_bench.hip): per-wave s_memtime stamps of the split-K form
+#define IGSTAMP(k) do { if (KSPLIT > 1) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dst_[k]) :: "memory"); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define IGSTAMP(k) do { } while (0)
+#endif
+
 template <typename T, int MODE, int CT, int PT, int KSPLIT>
 __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a)
 {
+#ifdef ZLY_IGEMM_DIAG
+    unsigned long long dst_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    IGSTAMP(0);                                                // wave start
     typedef typename Frag<T>::type F;
     constexpr int EPL = Frag<T>::EPL;
     constexpr int KSTEP = Frag<T>::KSTEP;
@@ -326,6 +337,11 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a)
 #pragma unroll
         for (int j = 0; j < DEPTH; ++j)
             if (s_begin + j < s_end) load_step(s_begin + j, wfr[j], afr[j]);
+        IGSTAMP(1);                                            // index arithmetic done, every load of the ring requested
+#ifdef ZLY_IGEMM_DIAG
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        IGSTAMP(2);                                            // ... and arrived
+#endif
         for (int s = s_begin; s < s_end; s += DEPTH) {
 #pragma unroll
             for (int j = 0; j < DEPTH; ++j) {
@@ -346,6 +362,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a)
         }
     }
 
+    IGSTAMP(3);                                                // MFMAs issued
     if constexpr (KSPLIT > 1) {
         // partial sums of waves 1..3 -> LDS -> wave 0 (each lane only ever touches its own column)
         __shared__ float red[(KSPLIT - 1) * CT * PT * 4 * 64];
@@ -359,6 +376,13 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a)
                         red[(((wave - 1) * CT + c) * PT + t) * 256 + r * 64 + lane] = acc[c][t][r];
         }
         __syncthreads();
+        IGSTAMP(4);                                            // partial sums in LDS, barrier passed
+#ifdef ZLY_IGEMM_DIAG
+        if (wave > 0 && lane == 0 && g_igemm_diag) {
+            unsigned long long* o = g_igemm_diag + (((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave) * 8;
+            for (int k = 0; k < 5; ++k) o[k] = dst_[k];
+        }
+#endif
         if (wave > 0) return;
 #pragma unroll
         for (int w = 0; w < KSPLIT - 1; ++w)
@@ -391,6 +415,17 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a)
         }
         epilogue_px<T, CT>(a, v, biasr, blockIdx.y * CT, kq, m);
     }
+#ifdef ZLY_IGEMM_DIAG
+    if (KSPLIT > 1) {
+        IGSTAMP(5);                                            // epilogue done, stores issued
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        IGSTAMP(6);                                            // stores acknowledged
+        if (lane == 0 && g_igemm_diag) {
+            unsigned long long* o = g_igemm_diag + (((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave) * 8;
+            for (int k = 0; k < 7; ++k) o[k] = dst_[k];
+        }
+    }
+#endif
 }
 
 // (Fetching the arguments up front -- all of them, or only the ~100 bytes the index arithmetic needs -- was measured SLOWER than the compiler's fetch-at-first-use on
