@@ -654,6 +654,7 @@ static int build_plan_device(zly_engine* e, PlanState* ps, std::string* err)
         s1.dump = (e->cfg.flags & ZLY_FLAG_DUMP_LOGITS) ? 1 : 0;
         s1.wgt0p = (const char*)e->d_weights + stem_w0p;
         s1.nw = e->sw.stem1_nw; s1.var = e->sw.stem1_var; s1.pgrid = e->sw.stem1_grid;
+        s1.small_tiles = (getenv("ZLY_STEM1_TW") || getenv("ZLY_STEM1_TH") || getenv("ZLY_STEM1_BIG_TILES")) ? 0 : 1;      // tuning aids given: keep the planned shape at every batch size
     }
     for (Op& op : e->ops) {
         if (op.kind != OP_HEAD) continue;

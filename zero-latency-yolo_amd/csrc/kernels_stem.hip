@@ -682,6 +682,17 @@ hipError_t launch_stem_model1(const Stem1Args& a0, int n, hipStream_t s)
     Stem1Args a = a0;
     if (a.st.Cout != 16 || a.TH < 1 || a.TW < 1 || a.out1_cs % 8 || a.out1_co % 8) return hipErrorInvalidValue;
     if (a.H1 * 2 != a.st.Ho || a.W1 * 2 != a.st.Wo) return hipErrorInvalidValue;      // even stem map: model.1 output = half of it
+    // small batches (the latency path): the planned 8 x 26 tiles are 52 workgroups per frame -- a fifth of the chip at batch 1, each walking 8 tile rounds per
+    // phase.  Halve the tile (width first, then height) while the launch has fewer workgroups than the chip holds: batch 1 step 0.1857 -> 0.1832 ms at 8 x 13.
+    // (a.small_tiles = 0: the engine's ZLY_STEM1_TW / ZLY_STEM1_TH were given, keep the planned shape.)
+    if (a.small_tiles) {
+        while ((long long)a.tiles_x * a.tiles_y * n < 2LL * g_stem1_cus) {
+            if (a.TW > 13 && a.TW % 2 == 0) a.TW /= 2;
+            else if (a.TH > 4 && a.TH % 2 == 0) a.TH /= 2;
+            else break;
+            a.tiles_x = (a.W1 + a.TW - 1) / a.TW; a.tiles_y = (a.H1 + a.TH - 1) / a.TH;
+        }
+    }
     const int nw = (a.nw == 12 || a.nw == 16) ? a.nw : STEM1_NW, var = a.var >= 2 ? 2 : a.var == 1 ? 1 : 0;
     if (var >= 1 && !a.wgt0p) return hipErrorInvalidValue;
     const size_t lds = stem1_lds_bytes(a.TH, a.TW, var);

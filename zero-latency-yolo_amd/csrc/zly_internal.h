@@ -136,6 +136,7 @@ struct Stem1Args {
     int nw, var;                              // waves per workgroup (0 = default), kernel variant (2 = persistent workgroups + input prefetch, 1 = one tile per workgroup, 0 = round 3's staging / tap order)
     int n;                                    // frames (set by launch_stem_model1)
     int pgrid;                                // var 2: workgroups of the persistent grid (0 = as many as stay resident)
+    int small_tiles;                          // 1: launch_stem_model1 halves the tile for launches with fewer workgroups than the chip holds (small batches)
     // set by launch_stem_model1 (host IEEE divides: the kernel used to spend six fp32 divides per thread on them)
     float inv_pw, inv_rw, inv_tw, inv_qb;     // 1 / patch row pitch, 1 / region width, 1 / tile width, 1 / quad blocks per patch row
     const void* wgt0p;                        // stem weights in the tap order of the conflict-free fragment reads (kernels_stem.hip: STEM1_TAP_SLOT)
