@@ -242,8 +242,23 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 8 : NW == 12 ? 6 : 4) void stem
         oy1 = ty * a.TH; ox1 = tx * a.TW;                    // model.1 output tile origin
     };
 
-    for (int u = tid; u < 2 * 9 * 512 / 16; u += NW * 64)
-        *reinterpret_cast<u32x4s*>(lw + (size_t)u * 16) = *reinterpret_cast<const u32x4s*>(static_cast<const unsigned char*>(a.w1) + (size_t)u * 16);
+    // model.1's weights (9 KB -> LDS, read in phase 3): REQUESTED here, stored after the first tile's pixels have been requested too (lw_store below).  As a
+    // copy loop at this place it was load -> s_waitcnt vmcnt(0) -> ds_write per iteration: one or two exposed global round trips at the head of every one of
+    // the 3328 workgroups of a batch-64 launch, before the frame descriptor and the pixels were even asked for.
+    constexpr int LW_UNITS = 2 * 9 * 512 / 16, LW_T = (LW_UNITS + NW * 64 - 1) / (NW * 64);
+    u32x4s lw_r[LW_T];
+#pragma unroll
+    for (int i = 0; i < LW_T; ++i) {
+        const int u = min(tid + i * NW * 64, LW_UNITS - 1);                 // clamped: no branch around the load (a surplus thread re-reads the last unit)
+        lw_r[i] = *reinterpret_cast<const u32x4s*>(static_cast<const unsigned char*>(a.w1) + (size_t)u * 16);
+    }
+    auto lw_store = [&]() {
+#pragma unroll
+        for (int i = 0; i < LW_T; ++i) {
+            const int u = tid + i * NW * 64;
+            if (u < LW_UNITS) *reinterpret_cast<u32x4s*>(lw + (size_t)u * 16) = lw_r[i];
+        }
+    };
 
     const bf16_t* wg0 = static_cast<const bf16_t*>(NEWP ? a.wgt0p : a.st.wgt);
     const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(wg0 + lane * 8);
@@ -325,6 +340,7 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 8 : NW == 12 ? 6 : 4) void stem
 
     int tile = PERS ? (int)blockIdx.x : (int)(blockIdx.y * tpf + blockIdx.x);
     issue_quads(tile);
+    lw_store();                                              // (the two barriers of the first tile lie between this store and the first read)
     for (; tile < total; tile += PERS ? (int)gridDim.x : total) {
     int f, oy1, ox1;
     tile_origin(tile, f, oy1, ox1);
